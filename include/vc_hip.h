@@ -1,0 +1,127 @@
+/* vc_hip.h -- C ABI of libvc_hip.so, the MI355X (gfx950) kernels behind the voice-conversion
+ * hot path of socom20/speech-cloner.
+ *
+ * The reference has no FFI: its boundary is the Python construct-and-run API
+ * (audio_lib.calc_MFCC_input, encoder.encoder_spec_phn, decoder.decoder_specs), whose
+ * arithmetic lives in librosa/scipy/TensorFlow-1.9 ops.  Each entry point below replaces the
+ * third-party op(s) one reference call site lowers to; the citation is the reference file:line.
+ * The Python modules in speech-cloner_amd/ (same names as the reference's) bind these with
+ * ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer named d_* is DEVICE memory (hipMalloc / torch.cuda tensor data_ptr);
+ *     pointers named h_* are host memory; plain sizes are element counts unless "_bytes".
+ *   - `stream` is a hipStream_t passed as void*; no entry point synchronises the stream or
+ *     allocates device memory except the create / destroy calls, so every launch call is
+ *     hipGraph-capturable.
+ *   - return value: 0 = VC_OK, otherwise a VC_ERR_* code; vc_last_error() gives the message of
+ *     the calling thread's last failure.  Nothing throws across the boundary.
+ *   - tensors are row-major; activations are [N, T, C] (time-major inside a window, channels
+ *     contiguous) exactly as the reference's TF tensors.
+ */
+#ifndef VC_HIP_H
+#define VC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VC_OK 0
+#define VC_ERR_INVALID 1      /* bad argument (shape, null pointer, unsupported size) */
+#define VC_ERR_HIP 2          /* a HIP runtime call failed */
+#define VC_ERR_WORKSPACE 3    /* workspace too small */
+#define VC_ERR_UNSUPPORTED 4
+
+#define VC_ABI_VERSION 1
+
+int vc_version(void);
+const char* vc_last_error(void);
+/* Name of the gfx target the code object was built for ("gfx950"). */
+const char* vc_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Signal front-end: audio_lib.calc_MFCC_input  (/root/reference/audio_lib.py:89-244)
+ *   amplitude normalisation (:125-126) -> pre-emphasis FIR (:12-28,:129-133) -> centred,
+ *   reflect-padded STFT (:141-147, librosa.core.stft) -> |.|^2 -> power_to_db (:155-157) ->
+ *   Slaney mel filterbank (:160-169) -> amplitude_to_db of the mel power (:172) -> DCT-II
+ *   (:176-179) -> first-coefficient / scale / delta / min-shift / clip post-processing
+ *   (:207-240), float32 time-major outputs (:244).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct vc_frontend_cfg {
+    int32_t sample_rate;               /* sr                       (default 16000) */
+    int32_t hop_length;                /* hop_length                               */
+    int32_t win_length;                /* win_length                               */
+    int32_t n_fft;                     /* n_fft (None in Python -> win_length)     */
+    int32_t n_mels;                    /* n_mels                                   */
+    int32_t n_mfcc;                    /* n_mfcc                                   */
+    float pre_emphasis;                /* 0.0 => filter skipped (audio_lib.py:129) */
+    float mean_abs_amp_norm;           /* 1.0 => skipped        (audio_lib.py:125) */
+    float mfcc_norm_factor;            /* 1.0 => skipped        (audio_lib.py:223) */
+    float M_dB_norm_factor;            /* 1.0 => skipped        (audio_lib.py:234) */
+    float P_dB_norm_factor;            /* 1.0 => skipped        (audio_lib.py:230) */
+    int32_t mfcc_normaleze_first_mfcc; /* bool                  (audio_lib.py:220) */
+    int32_t calc_mfcc_derivate;        /* bool                  (audio_lib.py:226) */
+    int32_t clip_output;               /* bool                  (audio_lib.py:237) */
+} vc_frontend_cfg;
+
+typedef struct vc_frontend_plan vc_frontend_plan;
+
+/* Host-only: the float64 tables a plan is built from, without touching the GPU.
+ * h_mel [n_mels, 1+n_fft/2] = librosa.filters.mel(sr, n_fft, n_mels, norm=1) (audio_lib.py:160-166),
+ * h_dct [n_mfcc, n_mels]    = librosa.filters.dct(n_mfcc, n_mels)            (audio_lib.py:176).
+ * Either pointer may be NULL. */
+int vc_frontend_host_tables(const vc_frontend_cfg* cfg, double* h_mel, double* h_dct);
+
+/* Builds the device-side constant tables (window, DFT twiddles, sparse mel filterbank, DCT
+ * basis).  h_window: host float64[win_length] analysis window (what
+ * scipy.signal.get_window(name, win_length, fftbins=True) returns), or NULL for periodic hann.
+ * Synchronous (small H2D copies). */
+int vc_frontend_plan_create(const vc_frontend_cfg* cfg, const double* h_window,
+                            vc_frontend_plan** out_plan);
+void vc_frontend_plan_destroy(vc_frontend_plan* plan);
+
+/* Number of frames for an L-sample utterance: 1 + L / hop_length  (audio_lib.py:52). */
+int32_t vc_frontend_num_frames(const vc_frontend_plan* plan, int32_t n_samples);
+/* Output feature widths: MFCC = n_mfcc * (1 | 2), mel = n_mels, power = 1 + n_fft/2. */
+int32_t vc_frontend_mfcc_width(const vc_frontend_plan* plan);
+int32_t vc_frontend_power_width(const vc_frontend_plan* plan);
+/* Copies the dense float64 mel matrix [n_mels, 1+n_fft/2] / DCT basis [n_mfcc, n_mels] the
+ * plan was built from into host buffers (for inspection and tests). */
+int vc_frontend_get_mel(const vc_frontend_plan* plan, double* h_out);
+int vc_frontend_get_dct(const vc_frontend_plan* plan, double* h_out);
+
+size_t vc_frontend_workspace_bytes(const vc_frontend_plan* plan, int32_t batch, int32_t max_samples);
+
+/* Batched feature extraction.
+ *   d_wav      float32 [batch, wav_stride]   (utterance b = row b, first lens[b] samples)
+ *   d_lens     int32   [batch] sample counts, or NULL => every utterance has max_samples
+ *              (each must satisfy n_fft/2 < len <= max_samples)
+ *   max_frames = 1 + max_samples / hop_length = row count of the outputs
+ *   d_mfcc     float32 [batch, max_frames, mfcc_width]
+ *   d_mel_db   float32 [batch, max_frames, n_mels]
+ *   d_pow_db   float32 [batch, max_frames, 1 + n_fft/2]
+ *              rows f >= 1 + lens[b]/hop of utterance b are zero-filled.
+ *   d_workspace / workspace_bytes: scratch of at least vc_frontend_workspace_bytes().
+ * Three launches on `stream`: per-utterance |x| partial sums; STFT power + mel + dB with
+ * per-tile max/min partials; finalize (top_db clip, min shift, DCT, delta, clip). */
+int vc_frontend_f32(const vc_frontend_plan* plan, const float* d_wav, const int32_t* d_lens,
+                    int32_t batch, int32_t max_samples, int32_t wav_stride,
+                    float* d_mfcc, float* d_mel_db, float* d_pow_db,
+                    void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* Same call restricted to a subset of its launches (measurement hook used by bench.py to time
+ * one kernel with HIP events): stage_mask bit0 = |x| partial sums, bit1 = STFT power/mel/dB,
+ * bit2 = finalize.  Later stages read what earlier ones left in the workspace. */
+int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, const int32_t* d_lens,
+                           int32_t batch, int32_t max_samples, int32_t wav_stride,
+                           float* d_mfcc, float* d_mel_db, float* d_pow_db,
+                           void* d_workspace, size_t workspace_bytes, void* stream,
+                           int32_t stage_mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VC_HIP_H */

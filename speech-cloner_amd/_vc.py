@@ -1,0 +1,93 @@
+"""ctypes binding of libvc_hip.so (C ABI declared in include/vc_hip.h).
+
+This is the only place Python touches the native library.  There is NO CPU fallback: if the
+library is missing or an entry point fails, an exception is raised (``VCError``).
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libvc_hip.so')
+
+VC_OK = 0
+
+
+class VCError(RuntimeError):
+    pass
+
+
+class FrontendCfg(C.Structure):
+    """struct vc_frontend_cfg (include/vc_hip.h)."""
+    _fields_ = [('sample_rate', C.c_int32), ('hop_length', C.c_int32), ('win_length', C.c_int32),
+                ('n_fft', C.c_int32), ('n_mels', C.c_int32), ('n_mfcc', C.c_int32),
+                ('pre_emphasis', C.c_float), ('mean_abs_amp_norm', C.c_float),
+                ('mfcc_norm_factor', C.c_float), ('M_dB_norm_factor', C.c_float),
+                ('P_dB_norm_factor', C.c_float),
+                ('mfcc_normaleze_first_mfcc', C.c_int32), ('calc_mfcc_derivate', C.c_int32),
+                ('clip_output', C.c_int32)]
+
+
+_lib = None
+_lock = threading.Lock()
+
+_P = C.c_void_p
+_SIGS = {
+    'vc_version': (C.c_int, []),
+    'vc_last_error': (C.c_char_p, []),
+    'vc_target_arch': (C.c_char_p, []),
+    'vc_frontend_host_tables': (C.c_int, [C.POINTER(FrontendCfg), _P, _P]),
+    'vc_frontend_plan_create': (C.c_int, [C.POINTER(FrontendCfg), _P, C.POINTER(_P)]),
+    'vc_frontend_plan_destroy': (None, [_P]),
+    'vc_frontend_num_frames': (C.c_int32, [_P, C.c_int32]),
+    'vc_frontend_mfcc_width': (C.c_int32, [_P]),
+    'vc_frontend_power_width': (C.c_int32, [_P]),
+    'vc_frontend_get_mel': (C.c_int, [_P, _P]),
+    'vc_frontend_get_dct': (C.c_int, [_P, _P]),
+    'vc_frontend_workspace_bytes': (C.c_size_t, [_P, C.c_int32, C.c_int32]),
+    'vc_frontend_f32': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P,
+                                  C.c_size_t, _P]),
+    'vc_frontend_stages_f32': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P,
+                                         C.c_size_t, _P, C.c_int32]),
+}
+
+
+def lib():
+    """Load (once) and return the ctypes handle of libvc_hip.so; raises VCError if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise VCError('native library %s not found -- run `python -c "import __graft_entry__ as g; '
+                          'g.build()"` (or make -C speech-cloner_amd/csrc); there is no CPU fallback'
+                          % LIB_PATH)
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc):
+    if rc != VC_OK:
+        msg = lib().vc_last_error()
+        raise VCError('libvc_hip error %d: %s' % (rc, msg.decode('utf-8', 'replace') if msg else '?'))
+
+
+def ptr(t):
+    """Device/host pointer of a torch tensor or numpy array (None -> NULL)."""
+    if t is None:
+        return None
+    if hasattr(t, 'data_ptr'):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

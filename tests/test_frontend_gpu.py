@@ -1,0 +1,110 @@
+"""Front-end parity on the MI355X: HIP path (through the C ABI) vs the CPU oracle and the
+committed golden vectors.
+
+Tolerances (features live in [-1, 1] after the 0.01 dB scaling):
+  MFCC / delta  abs 1e-4      mel dB  abs 1e-4      power dB  abs 2e-4
+The device computes in fp32 where librosa mixes f64/f32 (oracle header), so bit equality is
+not expected; frame counts and zero padding are exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import FE_KW, FE_KW_GENERIC
+from oracle import frontend_oracle as fo
+
+pytestmark = pytest.mark.gpu
+
+TOL = {'mfcc': 1e-4, 'mel': 1e-4, 'pdb': 2e-4}
+
+
+def _cmp(dev, ref, tol, what):
+    dev = np.asarray(dev)
+    assert dev.shape == ref.shape and dev.dtype == np.float32, (what, dev.shape, ref.shape)
+    err = np.abs(dev.astype(np.float64) - ref.astype(np.float64)).max()
+    assert err <= tol, '%s: max abs err %.3e > %.1e' % (what, err, tol)
+    return err
+
+
+def test_golden_default_ragged(golden_dir):
+    import audio_lib
+    g = np.load(os.path.join(golden_dir, 'frontend_default.npz'))
+    mfcc, mel, pdb = audio_lib.calc_MFCC_input_batch(g['wav'], g['lens'], **FE_KW)
+    Fmax = 1 + g['wav'].shape[1] // 80
+    assert mfcc.shape == (2, Fmax, 80) and mel.shape == (2, Fmax, 80) and pdb.shape == (2, Fmax, 201)
+    for b in range(2):
+        F = 1 + int(g['lens'][b]) // 80                       # exact integer contract
+        for name, t in (('mfcc', mfcc), ('mel', mel), ('pdb', pdb)):
+            _cmp(t[b, :F].cpu().numpy(), g['%s%d' % (name, b)], TOL[name], '%s[%d]' % (name, b))
+            assert float(t[b, F:].abs().max()) == 0.0 if F < Fmax else True   # zero padding rows
+
+
+def test_golden_generic_path(golden_dir):
+    import audio_lib
+    g = np.load(os.path.join(golden_dir, 'frontend_generic.npz'))
+    out = audio_lib.calc_MFCC_input(g['wav'][0], **FE_KW_GENERIC)
+    # unit norm factors: values are raw dB (|x| ~ 100) -> scale the tolerance by 100
+    for name, o in zip(('mfcc', 'mel', 'pdb'), out):
+        _cmp(o, g[name], 100 * TOL[name], name)
+
+
+def test_single_utterance_api_matches_oracle():
+    import audio_lib
+    for L, seed in ((16000, 1), (4079, 2), (401, 3), (51200, 4)):
+        wav = fo.synth_speech(1, L, seed=seed)[0]
+        dev = audio_lib.calc_MFCC_input(wav, **FE_KW)
+        ref = fo.calc_MFCC_input(wav, **FE_KW)
+        assert all(isinstance(d, np.ndarray) for d in dev)
+        for name, d, r in zip(('mfcc', 'mel', 'pdb'), dev, ref):
+            assert d.shape[0] == 1 + L // 80
+            _cmp(d, r, TOL[name], '%s L=%d' % (name, L))
+
+
+def test_noise_and_flag_variants():
+    import audio_lib
+    rng = np.random.RandomState(5)
+    wav = rng.standard_normal(12345).astype(np.float32)
+    for kw in (dict(FE_KW), dict(FE_KW, calc_mfcc_derivate=False), dict(FE_KW, clip_output=False),
+               dict(FE_KW, mfcc_normaleze_first_mfcc=False, pre_emphasis=0.0),
+               dict(FE_KW, hop_length=40, n_mels=128), dict(FE_KW, window='hamming')):
+        dev = audio_lib.calc_MFCC_input(wav, **kw)
+        ref = fo.calc_MFCC_input(wav, **kw)
+        for name, d, r in zip(('mfcc', 'mel', 'pdb'), dev, ref):
+            _cmp(d, r, TOL[name], '%s %s' % (name, sorted(kw.items())[:0]))
+
+
+def test_config2_full_size_properties():
+    """BASELINE config 2 (batch 32 x 4 s @ 16 kHz): size-independent properties at full size +
+    oracle comparison on a sample of utterances."""
+    import torch
+    import audio_lib
+    wav = fo.synth_speech(32, 64000, seed=0)
+    d_wav = torch.from_numpy(wav).cuda()
+    mfcc, mel, pdb = audio_lib.calc_MFCC_input_batch(d_wav, None, **FE_KW)
+    assert mfcc.shape == (32, 801, 80) and mel.shape == (32, 801, 80) and pdb.shape == (32, 801, 201)
+    assert torch.isfinite(mfcc).all() and torch.isfinite(mel).all() and torch.isfinite(pdb).all()
+    # clip range, min-shift => every utterance's minimum is exactly 0, top_db => max <= 0.8
+    assert float(mfcc.abs().max()) <= 1.0
+    assert torch.all(pdb.amin(dim=(1, 2)) == 0) and torch.all(mel.amin(dim=(1, 2)) == 0)
+    assert float(pdb.max()) <= 0.8 + 1e-6 and float(mel.max()) <= 0.8 + 1e-6
+    assert torch.all(mfcc[:, 0, 40:] == 0) and torch.all(mfcc[:, -1, 40:] == 0) and torch.all(mfcc[:, 0, 0] == 0)
+    # gain invariance (audio_lib.py:125-126): scaling the audio does not change the features
+    m2, l2, p2 = audio_lib.calc_MFCC_input_batch(d_wav * 0.125, None, **FE_KW)
+    assert float((m2 - mfcc).abs().max()) < 1e-5 and float((p2 - pdb).abs().max()) < 1e-5
+    # batching is transparent: utterance b alone == row b of the batch, bit for bit
+    m1, l1, p1 = audio_lib.calc_MFCC_input_batch(d_wav[5:6].contiguous(), None, **FE_KW)
+    assert torch.equal(m1[0], mfcc[5]) and torch.equal(l1[0], mel[5]) and torch.equal(p1[0], pdb[5])
+    for b in (0, 13, 31):
+        ref = fo.calc_MFCC_input(wav[b], **FE_KW)
+        for name, t, r in zip(('mfcc', 'mel', 'pdb'), (mfcc, mel, pdb), ref):
+            _cmp(t[b].cpu().numpy(), r, TOL[name], '%s[%d]' % (name, b))
+
+
+def test_errors_are_loud():
+    import torch
+    import _vc
+    import audio_lib
+    with pytest.raises(_vc.VCError):
+        audio_lib.calc_MFCC_input(np.zeros(100, dtype=np.float32), **FE_KW)      # L <= n_fft//2
+    with pytest.raises(ValueError):
+        audio_lib.calc_MFCC_input_batch(torch.zeros(2, 8000).cuda(), [8000, 9000], **FE_KW)
