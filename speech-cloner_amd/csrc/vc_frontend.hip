@@ -302,7 +302,8 @@ fe_finalize_kernel(FeArgs a, int g2) {
     float* D = reinterpret_cast<float*>(smem);         // [NC][NM+1]
     float* Mc = D + NC * DS;                           // [G+2][NM]  top_db-clipped raw mel dB
     float* Mf = Mc + (G + 2) * NM;                     // [G+2][NC]  scaled MFCC
-    float* sc = Mf + (G + 2) * NC;                     // [8] scalars
+    float* M0 = Mf + (G + 2) * NC;                     // [NM] frame-0 clipped mel dB
+    float* sc = M0 + NM;                               // [8] scalars
 
     const int b = blockIdx.y, tid = threadIdx.x;
     const int L = utt_len(a, b);
@@ -371,14 +372,9 @@ fe_finalize_kernel(FeArgs a, int g2) {
             Mc[i] = (f >= 0 && f < F) ? fmaxf(src[(size_t)f * NM + c], mfloor) : 0.0f;
         }
     }
-    // frame-0 first cepstral coefficient (audio_lib.py:221): sum_j D[0][j] * Mc0[j]
-    if (a.first_mfcc && tid < vc::WAVE) {
-        const float* src = a.mel_raw + row0 * NM;
-        float acc = 0.0f;
-        for (int j = tid; j < NM; j += vc::WAVE) acc = fmaf(a.t.dct[j], fmaxf(src[j], mfloor), acc);
-        acc = vc::wave_sum(acc);
-        if (tid == 0) sc[4] = acc;
-    }
+    // frame 0's clipped mel row: its first cepstral coefficient is subtracted from every frame
+    // (audio_lib.py:221)
+    for (int j = tid; j < NM; j += FE_THREADS) M0[j] = fmaxf(a.mel_raw[row0 * NM + j], mfloor);
     __syncthreads();
     {
         float* o = a.mel_db + (row0 + f0) * NM;
@@ -394,14 +390,18 @@ fe_finalize_kernel(FeArgs a, int g2) {
         }
     }
     // DCT-II (audio_lib.py:176-179) + first-coefficient shift + scale (:220-224)
-    const float c0 = a.first_mfcc ? sc[4] : 0.0f;
     for (int i = tid; i < (G + 2) * NC; i += FE_THREADS) {
         const int r = i / NC, c = i - r * NC;
         const float* d = D + c * DS;
         const float* m = Mc + r * NM;
         float acc = 0.0f;
         for (int j = 0; j < NM; ++j) acc = fmaf(d[j], m[j], acc);
-        if (c == 0) acc -= c0;
+        if (c == 0 && a.first_mfcc) {
+            // same FMA chain on frame 0 => frame 0's own coefficient cancels to exactly 0
+            float c0 = 0.0f;
+            for (int j = 0; j < NM; ++j) c0 = fmaf(d[j], M0[j], c0);
+            acc -= c0;
+        }
         if (a.mfcc_norm != 1.0f) acc *= a.mfcc_norm;
         Mf[i] = acc;
     }
@@ -675,7 +675,7 @@ int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, con
     }
     if (stage_mask & 4) {
         const int nt3 = (max_frames + FE_G3 - 1) / FE_G3;
-        const size_t lds = ((size_t)c.n_mfcc * (c.n_mels + 1) + (size_t)(FE_G3 + 2) * (c.n_mels + c.n_mfcc) + 8) * 4;
+        const size_t lds = ((size_t)c.n_mfcc * (c.n_mels + 1) + (size_t)(FE_G3 + 2) * (c.n_mels + c.n_mfcc) + c.n_mels + 8) * 4;
         VC_REQUIRE(lds <= 160 * 1024, "n_mels/n_mfcc too large for the finalize kernel's LDS tile (%zu B)", lds);
         hipLaunchKernelGGL(fe_finalize_kernel, dim3(nt3, batch), dim3(FE_THREADS), lds, st, a, G);
     }
