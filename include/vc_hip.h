@@ -121,6 +121,93 @@ int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, con
                            void* d_workspace, size_t workspace_bytes, void* stream,
                            int32_t stage_mask);
 
+/* ------------------------------------------------------------------------------------------
+ * Network blocks: modules.py (/root/reference/modules.py:39-356) lowered to four kernels.
+ * dtype codes for activations/weights: */
+#define VC_F32 0
+#define VC_BF16 1
+/* activation codes */
+#define VC_ACT_NONE 0
+#define VC_ACT_RELU 1
+#define VC_ACT_SIGMOID 2
+#define VC_ACT_TANH 3
+/* vc_gemm_desc.mode */
+#define VC_GEMM_PLAIN 0
+#define VC_GEMM_HIGHWAY 1
+#define VC_GEMM_MAX_GROUPS 32
+
+/* One implicit-GEMM launch:  C[m, c_off + n] = epilogue( sum_kk A[m, kk] * Bt[n, kk] ).
+ *
+ * A is a Toeplitz VIEW of the activation tensor X [M = N_windows*T rows, Cin channels, row
+ * stride ldx]:  A[m, j*Cin + c] = X[m + j - pad_l, c]  if 0 <= (m mod T) + j - pad_l < T else 0,
+ * which is exactly tf.layers.conv1d(padding="SAME", stride 1, no bias) on [N,T,Cin] with a
+ * kernel stored [taps, Cin, Cout] (modules.py:104-140; pad_l = (taps-1)/2).  taps = 1 gives
+ * tf.layers.dense (modules.py:291-293, 315-317; encoder.py:109; decoder.py:127,179).
+ * Bt is the kernel TRANSPOSED to [Cout, taps*Cin] (K contiguous), dtype = `dtype`.
+ *
+ * Grouped launch (n_groups > 1) = conv1d_banks (modules.py:144-166): group g has its own
+ * taps/pad_l/K/Bt and writes columns [c_off, c_off + N) of the shared output (the concat).
+ *
+ * Optional prologue on A (applied per element, in this order):
+ *   pro_scale/pro_shift [Cin] affine, pro_relu, pro_pool: max(A[r], A[r+1]) along time with the
+ *   TF "same" rule out[T-1] = x[T-1]  (tf.layers.max_pooling1d(2,1,"same"), modules.py:331).
+ * Epilogue: v = acc * epi_scale[c] + epi_shift[c] (NULL scale = 1, NULL shift = 0; this is the
+ *   dense bias or the folded inference FusedBatchNorm of modules.py:39-102), activation,
+ *   + residual R[m, n] (modules.py:340), stored as float32 (out_f32 != 0) or as `dtype`.
+ * mode VC_GEMM_HIGHWAY (modules.py:297-319): Bt holds [32 rows of dense1^T | 32 rows of
+ *   dense2^T] interleaved per 32 output units (N = 64*ceil(H/32) rows, zero-padded), epi_shift
+ *   the biases in the same order; output [M, H]: relu(h)*sig(t) + x*(1 - sig(t)), x = X.
+ * All device pointers; scale/shift vectors are float32. */
+typedef struct vc_gemm_group {
+    const void* d_Bt;   /* [N, K] transposed kernel, row stride K */
+    int32_t K;          /* taps * Cin (multiple of 4 for f32, 8 for bf16) */
+    int32_t taps;
+    int32_t pad_l;
+    int32_t c_off;      /* first output column of this group */
+} vc_gemm_group;
+
+typedef struct vc_gemm_desc {
+    int32_t dtype;              /* VC_F32 | VC_BF16: type of X, Bt, R (and C unless out_f32) */
+    int32_t mode;               /* VC_GEMM_PLAIN | VC_GEMM_HIGHWAY */
+    const void* d_X;
+    int32_t M, T, Cin, ldx;
+    int32_t N;                  /* output columns per group */
+    int32_t n_groups;
+    vc_gemm_group groups[VC_GEMM_MAX_GROUPS];
+    const float* d_pro_scale;   /* [Cin] or NULL */
+    const float* d_pro_shift;   /* [Cin] or NULL */
+    int32_t pro_relu, pro_pool;
+    const float* d_epi_scale;   /* [c_off + N] or NULL */
+    const float* d_epi_shift;   /* [c_off + N] or NULL */
+    int32_t act;
+    const void* d_R;            /* residual [M, ldr] or NULL */
+    int32_t ldr;
+    void* d_C;
+    int32_t ldc;
+    int32_t out_f32;
+} vc_gemm_desc;
+
+int vc_conv_gemm(const vc_gemm_desc* desc, void* stream);
+
+/* softmax + argmax over the last axis (encoder.py:110-111): logits float32 [M, ldl >= N] ->
+ * probabilities (dtype out_dtype, row stride ldp, columns [N, ldp) zero-filled so the
+ * decoder's first dense can read 16-byte rows) and int32 class ids (first maximum). */
+int vc_softmax_argmax(const float* d_logits, int32_t M, int32_t N, int32_t ldl,
+                      void* d_prob, int32_t ldp, int32_t out_dtype, int32_t* d_class, void* stream);
+
+/* Bidirectional GRU recurrence (modules.py:168-204 -> tf.nn.bidirectional_dynamic_rnn over
+ * tf.contrib.rnn.GRUCell):  g = sigmoid(xg + h Wg_h);  r,u = split(g) (r first);
+ * c = tanh(xc + (r*h) Wc_h);  h' = u*h + (1-u)*c, zero initial state, backward direction runs
+ * t = T-1..0.  The input halves of the cell matmuls are hoisted into one GEMM beforehand:
+ *   d_xproj float32 [n_seq*T, 6H] = x @ [Wg_x^fw | Wc_x^fw | Wg_x^bw | Wc_x^bw] + biases.
+ *   d_Wh[dir]: recurrent weights [H, 3H] = [Wg_h | Wc_h] (rows = h index), dtype w_dtype.
+ *   d_out [n_seq*T, 2H] (dtype out_dtype): fw in columns [0,H), bw in [H,2H). */
+int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw, int32_t w_dtype,
+                 int32_t n_seq, int32_t T, int32_t H, void* d_out, int32_t out_dtype, void* stream);
+
+/* float32 <-> bf16 conversion of a contiguous buffer (weights preparation, I/O). */
+int vc_convert(const void* d_src, int32_t src_dtype, void* d_dst, int32_t dst_dtype, size_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,31 @@ class FrontendCfg(C.Structure):
                 ('clip_output', C.c_int32)]
 
 
+VC_F32, VC_BF16 = 0, 1
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3
+GEMM_PLAIN, GEMM_HIGHWAY = 0, 1
+GEMM_MAX_GROUPS = 32
+
+
+class GemmGroup(C.Structure):
+    """struct vc_gemm_group (include/vc_hip.h)."""
+    _fields_ = [('d_Bt', C.c_void_p), ('K', C.c_int32), ('taps', C.c_int32), ('pad_l', C.c_int32),
+                ('c_off', C.c_int32)]
+
+
+class GemmDesc(C.Structure):
+    """struct vc_gemm_desc (include/vc_hip.h)."""
+    _fields_ = [('dtype', C.c_int32), ('mode', C.c_int32), ('d_X', C.c_void_p),
+                ('M', C.c_int32), ('T', C.c_int32), ('Cin', C.c_int32), ('ldx', C.c_int32),
+                ('N', C.c_int32), ('n_groups', C.c_int32),
+                ('groups', GemmGroup * GEMM_MAX_GROUPS),
+                ('d_pro_scale', C.c_void_p), ('d_pro_shift', C.c_void_p),
+                ('pro_relu', C.c_int32), ('pro_pool', C.c_int32),
+                ('d_epi_scale', C.c_void_p), ('d_epi_shift', C.c_void_p), ('act', C.c_int32),
+                ('d_R', C.c_void_p), ('ldr', C.c_int32), ('d_C', C.c_void_p), ('ldc', C.c_int32),
+                ('out_f32', C.c_int32)]
+
+
 _lib = None
 _lock = threading.Lock()
 
@@ -49,6 +74,10 @@ _SIGS = {
                                   C.c_size_t, _P]),
     'vc_frontend_stages_f32': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P,
                                          C.c_size_t, _P, C.c_int32]),
+    'vc_conv_gemm': (C.c_int, [C.POINTER(GemmDesc), _P]),
+    'vc_softmax_argmax': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
+    'vc_gru_bidir': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
+    'vc_convert': (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_size_t, _P]),
 }
 
 

@@ -1,0 +1,348 @@
+// Implicit-GEMM kernel for the network blocks of /root/reference/modules.py on gfx950 MFMA:
+// tf.layers.dense (:291-293,315-317), tf.layers.conv1d SAME/no-bias (:104-140), conv1d_banks
+// (:144-166, grouped launch), max_pooling1d(2,1,same) (:331, fused into the consumer's operand
+// load), inference FusedBatchNorm (:39-102, folded scale/shift epilogue), residual add (:340)
+// and highwaynet (:297-319, paired-column epilogue).  Contract: include/vc_hip.h (vc_gemm_desc).
+//
+// Tiling: 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 2 x 2 MFMA
+// tiles of 32 x 32.  K is consumed in slabs of 128 bytes per row (32 f32 / 64 bf16) staged
+// through a double-buffered LDS image with 144-byte rows (16-byte pad => the four 16-lane groups
+// of ds_read_b128 hit 16 distinct slots).  Both operands are K-contiguous (A is a Toeplitz view
+// of the activations, B is the pre-transposed kernel), so global loads are 16 B/lane and a lane's
+// MFMA fragment is one ds_read_b128:
+//   f32 : v_mfma_f32_32x32x2_f32, exact f32 fma chain; the 4 floats of a 16-B chunk feed 4 MFMAs
+//   bf16: v_mfma_f32_32x32x16_bf16, f32 accumulate; a 16-B chunk is one MFMA's 8-element fragment
+// Register-staged pipeline: global loads of slab t+1 are issued before the MFMAs of slab t and
+// written to the other LDS buffer after them (one barrier per slab).
+#include <hip/hip_runtime.h>
+
+#include "vc_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128, BN = 128;
+constexpr int ROWB = 144;                      // LDS row pitch in bytes (128 data + 16 pad)
+constexpr int TILE_BYTES = BM * ROWB;          // 18,432
+constexpr int GEMM_THREADS = 256;
+constexpr int GEMM_LDS = 4 * TILE_BYTES;       // A0 B0 A1 B1 = 73,728
+
+template <typename T> struct Tr;
+template <> struct Tr<float> {
+    static constexpr int VEC = 4, BK = 32;
+    typedef f32x4 vec_t;
+};
+template <> struct Tr<__bf16> {
+    static constexpr int VEC = 8, BK = 64;
+    typedef bf16x8 vec_t;
+};
+
+struct KGroup {
+    const void* Bt;
+    int32_t K, taps, pad_l, c_off;
+};
+
+struct KArgs {
+    const void* X;
+    int32_t M, T, Cin, ldx, N, n_groups;
+    const float* pro_scale;
+    const float* pro_shift;
+    int32_t pro_relu, pro_pool;
+    const float* epi_scale;
+    const float* epi_shift;
+    int32_t act;
+    const void* R;
+    int32_t ldr;
+    void* C;
+    int32_t ldc, out_f32;
+    KGroup g[VC_GEMM_MAX_GROUPS];
+};
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+    switch (act) {
+        case VC_ACT_RELU: return fmaxf(v, 0.0f);
+        case VC_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+        case VC_ACT_TANH: return tanhf(v);
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(__bf16 v) { return (float)v; }
+
+template <typename T> __device__ __forceinline__ void store_out(void* C, size_t idx, float v, int out_f32) {
+    if (out_f32) reinterpret_cast<float*>(C)[idx] = v;
+    else reinterpret_cast<T*>(C)[idx] = (T)v;
+}
+
+// per-channel affine + relu on a 16-byte operand vector
+__device__ __forceinline__ f32x4 pro_apply(f32x4 v, const float* sc, const float* sh, int c, int relu) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float x = v[e];
+        if (sc) x = x * sc[c + e] + sh[c + e];
+        if (relu) x = fmaxf(x, 0.0f);
+        v[e] = x;
+    }
+    return v;
+}
+__device__ __forceinline__ bf16x8 pro_apply(bf16x8 v, const float* sc, const float* sh, int c, int relu) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        float x = (float)v[e];
+        if (sc) x = x * sc[c + e] + sh[c + e];
+        if (relu) x = fmaxf(x, 0.0f);
+        v[e] = (__bf16)x;
+    }
+    return v;
+}
+__device__ __forceinline__ f32x4 vmax(f32x4 a, f32x4 b) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] = fmaxf(a[e], b[e]);
+    return a;
+}
+__device__ __forceinline__ bf16x8 vmax(bf16x8 a, bf16x8 b) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = ((float)a[e] >= (float)b[e]) ? a[e] : b[e];
+    return a;
+}
+
+template <typename T> __device__ __forceinline__ void mma_slab(const char* As, const char* Bs, int wm, int wn,
+                                                               int lane, f32x16 (&acc)[2][2]);
+
+template <> __device__ __forceinline__ void mma_slab<float>(const char* As, const char* Bs, int wm, int wn,
+                                                            int lane, f32x16 (&acc)[2][2]) {
+    const int i = lane & 31, h = lane >> 5;
+    const char* ap = As + (wm * 64 + i) * ROWB + h * 16;
+    const char* bp = Bs + (wn * 64 + i) * ROWB + h * 16;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        f32x4 av[2], bv[2];
+        av[0] = *reinterpret_cast<const f32x4*>(ap + p * 32);
+        av[1] = *reinterpret_cast<const f32x4*>(ap + 32 * ROWB + p * 32);
+        bv[0] = *reinterpret_cast<const f32x4*>(bp + p * 32);
+        bv[1] = *reinterpret_cast<const f32x4*>(bp + 32 * ROWB + p * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][q], bv[ni][q], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+template <> __device__ __forceinline__ void mma_slab<__bf16>(const char* As, const char* Bs, int wm, int wn,
+                                                             int lane, f32x16 (&acc)[2][2]) {
+    const int i = lane & 31, h = lane >> 5;
+    const char* ap = As + (wm * 64 + i) * ROWB + h * 16;
+    const char* bp = Bs + (wn * 64 + i) * ROWB + h * 16;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        bf16x8 av[2], bv[2];
+        av[0] = *reinterpret_cast<const bf16x8*>(ap + s * 32);
+        av[1] = *reinterpret_cast<const bf16x8*>(ap + 32 * ROWB + s * 32);
+        bv[0] = *reinterpret_cast<const bf16x8*>(bp + s * 32);
+        bv[1] = *reinterpret_cast<const bf16x8*>(bp + 32 * ROWB + s * 32);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+    }
+}
+
+template <typename T, int MODE>
+__global__ void __launch_bounds__(GEMM_THREADS, 2)
+gemm_kernel(KArgs a) {
+    typedef typename Tr<T>::vec_t vec_t;
+    constexpr int VEC = Tr<T>::VEC, BK = Tr<T>::BK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const KGroup grp = a.g[a.n_groups - 1 - (int)blockIdx.y];   // heaviest group first
+    const int ntn = (a.N + BN - 1) / BN;
+    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int K = grp.K, Cin = a.Cin, Tn = a.T;
+    const int nk = (K + BK - 1) / BK;
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* Bt = reinterpret_cast<const T*>(grp.Bt);
+
+    const int sc = tid & 7, sr = tid >> 3;
+    int a_t[4];
+    bool a_ok[4], b_ok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int m = m0 + sr + 32 * p;
+        a_ok[p] = m < a.M;
+        a_t[p] = m % Tn;
+        b_ok[p] = (n0 + sr + 32 * p) < a.N;
+    }
+    const bool has_pro = (a.pro_scale != nullptr) || a.pro_relu;
+
+    vec_t ra[4], rb[4];
+    auto gload = [&](int kt) {
+        const int kk = kt * BK + sc * VEC;
+        const bool kok = kk < K;
+        int j = 0, c = kk;
+        if (grp.taps > 1) { j = kk / Cin; c = kk - j * Cin; }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            vec_t va = {}, vb = {};
+            if (kok && a_ok[p]) {
+                const int tt = a_t[p] + j - grp.pad_l;
+                if (tt >= 0 && tt < Tn) {
+                    const T* ptr = X + (size_t)(m0 + sr + 32 * p + j - grp.pad_l) * a.ldx + c;
+                    va = *reinterpret_cast<const vec_t*>(ptr);
+                    if (has_pro) va = pro_apply(va, a.pro_scale, a.pro_shift, c, a.pro_relu);
+                    if (a.pro_pool && tt + 1 < Tn) {
+                        vec_t v2 = *reinterpret_cast<const vec_t*>(ptr + a.ldx);
+                        if (has_pro) v2 = pro_apply(v2, a.pro_scale, a.pro_shift, c, a.pro_relu);
+                        va = vmax(va, v2);
+                    }
+                }
+            }
+            if (kok && b_ok[p]) vb = *reinterpret_cast<const vec_t*>(Bt + (size_t)(n0 + sr + 32 * p) * K + kk);
+            ra[p] = va;
+            rb[p] = vb;
+        }
+    };
+    auto lstore = [&](int buf) {
+        char* As = smem + buf * 2 * TILE_BYTES;
+        char* Bs = As + TILE_BYTES;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            *reinterpret_cast<vec_t*>(As + (sr + 32 * p) * ROWB + sc * 16) = ra[p];
+            *reinterpret_cast<vec_t*>(Bs + (sr + 32 * p) * ROWB + sc * 16) = rb[p];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload(kt + 1);
+        const char* As = smem + (kt & 1) * 2 * TILE_BYTES;
+        mma_slab<T>(As, As + TILE_BYTES, wm, wn, lane, acc);
+        if (more) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---------------------------------------------------------------------------- epilogue
+    const int i = lane & 31, h = lane >> 5;
+    if (MODE == VC_GEMM_PLAIN) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int gn = n0 + wn * 64 + ni * 32 + i;
+            if (gn >= a.N) continue;
+            const int oc = grp.c_off + gn;
+            const float s = a.epi_scale ? a.epi_scale[oc] : 1.0f;
+            const float b = a.epi_shift ? a.epi_shift[oc] : 0.0f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (gm >= a.M) continue;
+                    float v = act_fn(acc[mi][ni][r] * s + b, a.act);
+                    if (a.R) v += to_f32(reinterpret_cast<const T*>(a.R)[(size_t)gm * a.ldr + gn]);
+                    store_out<T>(a.C, (size_t)gm * a.ldc + oc, v, a.out_f32);
+                }
+            }
+        }
+    } else {
+        // highway: columns come in (32 x dense1 | 32 x dense2) pairs; output unit index:
+        const int hc = (n0 + wn * 64) / 2 + i;
+        const int Hn = Cin;                               // highway keeps the width (modules.py:311-312)
+        if (hc < Hn) {
+            const int gnH = n0 + wn * 64 + i, gnT = gnH + 32;
+            const float bH = a.epi_shift ? a.epi_shift[gnH] : 0.0f;
+            const float bT = a.epi_shift ? a.epi_shift[gnT] : 0.0f;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (gm >= a.M) continue;
+                    const float hv = fmaxf(acc[mi][0][r] + bH, 0.0f);
+                    const float tv = 1.0f / (1.0f + __expf(-(acc[mi][1][r] + bT)));
+                    const float xv = to_f32(X[(size_t)gm * a.ldx + hc]);
+                    store_out<T>(a.C, (size_t)gm * a.ldc + hc, hv * tv + xv * (1.0f - tv), a.out_f32);
+                }
+            }
+        }
+    }
+}
+
+template <typename T> int launch(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
+    const int ntm = (d->M + BM - 1) / BM, ntn = (d->N + BN - 1) / BN;
+    dim3 grid(ntm * ntn, d->n_groups), block(GEMM_THREADS);
+    if (d->mode == VC_GEMM_HIGHWAY) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, VC_GEMM_HIGHWAY>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((gemm_kernel<T, VC_GEMM_HIGHWAY>), grid, block, GEMM_LDS, st, ka);
+    } else {
+        static bool attr_done = false;
+        if (!attr_done) {
+            VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, VC_GEMM_PLAIN>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((gemm_kernel<T, VC_GEMM_PLAIN>), grid, block, GEMM_LDS, st, ka);
+    }
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+}  // namespace
+
+extern "C" int vc_conv_gemm(const vc_gemm_desc* d, void* stream) {
+    VC_REQUIRE(d != nullptr, "desc is NULL");
+    VC_REQUIRE(d->dtype == VC_F32 || d->dtype == VC_BF16, "bad dtype %d", d->dtype);
+    VC_REQUIRE(d->mode == VC_GEMM_PLAIN || d->mode == VC_GEMM_HIGHWAY, "bad mode %d", d->mode);
+    VC_REQUIRE(d->d_X && d->d_C, "NULL X or C");
+    VC_REQUIRE(d->M > 0 && d->T > 0 && d->Cin > 0 && d->N > 0, "bad shape M=%d T=%d Cin=%d N=%d", d->M, d->T, d->Cin, d->N);
+    VC_REQUIRE(d->M % d->T == 0, "M (%d) must be a multiple of T (%d)", d->M, d->T);
+    VC_REQUIRE(d->n_groups >= 1 && d->n_groups <= VC_GEMM_MAX_GROUPS, "n_groups out of range: %d", d->n_groups);
+    const int vec = d->dtype == VC_F32 ? 4 : 8;
+    VC_REQUIRE(d->Cin % vec == 0 && d->ldx % vec == 0 && d->ldx >= d->Cin,
+               "Cin (%d) and ldx (%d) must be multiples of %d with ldx >= Cin", d->Cin, d->ldx, vec);
+    VC_REQUIRE((reinterpret_cast<uintptr_t>(d->d_X) & 15) == 0, "X must be 16-byte aligned");
+    VC_REQUIRE(!(d->d_pro_scale == nullptr) == !(d->d_pro_shift == nullptr), "pro_scale and pro_shift go together");
+    if (d->mode == VC_GEMM_HIGHWAY)
+        VC_REQUIRE(d->n_groups == 1 && d->groups[0].taps == 1 && d->N % 64 == 0 && d->N >= 2 * d->Cin && !d->d_R,
+                   "highway mode: one group, taps 1, N = 64*ceil(H/32) paired columns, no residual");
+    KArgs ka;
+    ka.X = d->d_X; ka.M = d->M; ka.T = d->T; ka.Cin = d->Cin; ka.ldx = d->ldx; ka.N = d->N; ka.n_groups = d->n_groups;
+    ka.pro_scale = d->d_pro_scale; ka.pro_shift = d->d_pro_shift; ka.pro_relu = d->pro_relu; ka.pro_pool = d->pro_pool;
+    ka.epi_scale = d->d_epi_scale; ka.epi_shift = d->d_epi_shift; ka.act = d->act;
+    ka.R = d->d_R; ka.ldr = d->ldr; ka.C = d->d_C; ka.ldc = d->ldc; ka.out_f32 = d->out_f32;
+    for (int g = 0; g < d->n_groups; ++g) {
+        const vc_gemm_group& gg = d->groups[g];
+        VC_REQUIRE(gg.d_Bt != nullptr && (reinterpret_cast<uintptr_t>(gg.d_Bt) & 15) == 0, "group %d: Bt NULL or misaligned", g);
+        VC_REQUIRE(gg.taps >= 1 && gg.K == gg.taps * d->Cin, "group %d: K (%d) != taps (%d) * Cin (%d)", g, gg.K, gg.taps, d->Cin);
+        VC_REQUIRE(gg.pad_l >= 0 && gg.pad_l < gg.taps, "group %d: bad pad_l %d", g, gg.pad_l);
+        VC_REQUIRE(gg.c_off >= 0 && gg.c_off + d->N <= d->ldc || d->mode == VC_GEMM_HIGHWAY, "group %d: columns exceed ldc", g);
+        ka.g[g].Bt = gg.d_Bt; ka.g[g].K = gg.K; ka.g[g].taps = gg.taps; ka.g[g].pad_l = gg.pad_l; ka.g[g].c_off = gg.c_off;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return d->dtype == VC_F32 ? launch<float>(d, ka, st) : launch<__bf16>(d, ka, st);
+}

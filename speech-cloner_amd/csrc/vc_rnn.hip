@@ -1,0 +1,212 @@
+// Recurrent + row-wise kernels of the network path (contract: include/vc_hip.h):
+//   vc_gru_bidir       bidirectional GRU recurrence (/root/reference/modules.py:168-204)
+//   vc_softmax_argmax  tf.nn.softmax + tf.argmax (/root/reference/encoder.py:110-111)
+//   vc_convert         f32 <-> bf16
+//
+// GRU: the time loop is strictly serial (400 steps per direction), so one workgroup owns one
+// (window, direction) pair for the whole sequence: h never leaves the CU (LDS), the recurrent
+// weights stay on chip whenever they fit (LDS here; registers in gru_resident below) and only the
+// hoisted input projections stream in (prefetched one step ahead).  No cross-CU exchange per
+// step -- that costs >= 1 us on this chip (MI355X_MICROARCH.md, hand-off price list), more than a
+// whole step.
+#include <hip/hip_runtime.h>
+
+#include "vc_common.h"
+
+namespace {
+
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float ld_w(const float* p) { return *p; }
+__device__ __forceinline__ float ld_w(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+struct GruArgs {
+    const float* xproj;     // [n_seq*T, 6H]
+    const void* Wh[2];      // [H, 3H] per direction
+    void* out;              // [n_seq*T, 2H]
+    int32_t n_seq, T, H, out_bf16, w_in_lds;
+};
+
+template <typename T> __device__ __forceinline__ void st_out(void* o, size_t i, float v, int bf) {
+    if (bf) reinterpret_cast<__bf16*>(o)[i] = (__bf16)v;
+    else reinterpret_cast<float*>(o)[i] = v;
+}
+
+// Generic recurrence: any H.  Thread (col, ks): column `col` of the phase's weight block, K-slice
+// ks of KS (KS a power of two <= 64, lanes of one column adjacent => shuffle reduction).
+template <typename WT>
+__global__ void __launch_bounds__(512)
+gru_generic_kernel(GruArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.H, H3 = 3 * H, NT = blockDim.x, tid = threadIdx.x;
+    float* h = reinterpret_cast<float*>(smem);      // [H]
+    float* rh = h + H;                              // [H]
+    float* u = rh + H;                              // [H]
+    WT* wl = reinterpret_cast<WT*>(u + H);          // [H][3H] when cached
+    const int seq = blockIdx.x, dir = blockIdx.y;
+    const WT* Wg = reinterpret_cast<const WT*>(a.Wh[dir]);
+    if (a.w_in_lds) {
+        for (int i = tid; i < H * H3; i += NT) wl[i] = Wg[i];
+        Wg = wl;
+    }
+    for (int i = tid; i < H; i += NT) h[i] = 0.0f;
+
+    int KS1 = 1, KS2 = 1;
+    while (KS1 * 2 <= 64 && KS1 * 2 * 2 * H <= NT) KS1 *= 2;
+    while (KS2 * 2 <= 64 && KS2 * 2 * H <= NT) KS2 *= 2;
+    const int col1 = tid / KS1, ks1 = tid % KS1;      // gate column in [0, 2H)
+    const int col2 = tid / KS2, ks2 = tid % KS2;      // candidate column in [0, H)
+    const bool act1 = col1 < 2 * H, act2 = col2 < H;
+    const size_t xrow = 6 * (size_t)H;
+    const float* xbase = a.xproj + (size_t)seq * a.T * xrow + (size_t)dir * H3;
+    __syncthreads();
+
+    int t = dir ? a.T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    float xg = (act1 && ks1 == 0) ? xbase[(size_t)t * xrow + col1] : 0.0f;
+    float xc = (act2 && ks2 == 0) ? xbase[(size_t)t * xrow + 2 * H + col2] : 0.0f;
+    for (int step = 0; step < a.T; ++step, t += dt) {
+        // prefetch next step's input projections
+        float xg_n = 0.0f, xc_n = 0.0f;
+        if (step + 1 < a.T) {
+            if (act1 && ks1 == 0) xg_n = xbase[(size_t)(t + dt) * xrow + col1];
+            if (act2 && ks2 == 0) xc_n = xbase[(size_t)(t + dt) * xrow + 2 * H + col2];
+        }
+        // phase 1: gates
+        float acc = 0.0f;
+        if (act1) {
+            const WT* w = Wg + col1;
+            for (int k = ks1; k < H; k += KS1) acc = fmaf(h[k], ld_w(w + (size_t)k * H3), acc);
+        }
+        for (int o = KS1 >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (act1 && ks1 == 0) {
+            const float g = sigmoidf_(acc + xg);
+            if (col1 < H) rh[col1] = g * h[col1];       // r first (GRUCell split order)
+            else u[col1 - H] = g;
+        }
+        __syncthreads();
+        // phase 2: candidate
+        float acc2 = 0.0f;
+        if (act2) {
+            const WT* w = Wg + 2 * H + col2;
+            for (int k = ks2; k < H; k += KS2) acc2 = fmaf(rh[k], ld_w(w + (size_t)k * H3), acc2);
+        }
+        for (int o = KS2 >> 1; o > 0; o >>= 1) acc2 += __shfl_xor(acc2, o, 64);
+        float hn = 0.0f;
+        if (act2 && ks2 == 0) {
+            const float c = tanhf(acc2 + xc);
+            const float uu = u[col2];
+            hn = uu * h[col2] + (1.0f - uu) * c;
+        }
+        __syncthreads();                                // everyone done reading h / rh
+        if (act2 && ks2 == 0) {
+            h[col2] = hn;
+            st_out<WT>(a.out, ((size_t)seq * a.T + t) * 2 * H + (size_t)dir * H + col2, hn, a.out_bf16);
+        }
+        __syncthreads();
+        xg = xg_n;
+        xc = xc_n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+softmax_argmax_kernel(const float* logits, int M, int N, int ldl, void* prob, int ldp, int out_bf16, int32_t* cls) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* x = logits + (size_t)row * ldl;
+    float mx = -3.402823466e38f;
+    int mi = 0x7fffffff;
+    for (int c = lane; c < N; c += 64) {
+        const float v = x[c];
+        if (v > mx) { mx = v; mi = c; }                 // first maximum within the lane's stride
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+    }
+    float s = 0.0f;
+    for (int c = lane; c < N; c += 64) s += expf(x[c] - mx);
+    s = vc::wave_sum(s);
+    const float inv = 1.0f / s;
+    for (int c = lane; c < ldp; c += 64) {
+        const float p = c < N ? expf(x[c] - mx) * inv : 0.0f;
+        if (out_bf16) reinterpret_cast<__bf16*>(prob)[(size_t)row * ldp + c] = (__bf16)p;
+        else reinterpret_cast<float*>(prob)[(size_t)row * ldp + c] = p;
+    }
+    if (cls && lane == 0) cls[row] = mi;
+}
+
+__global__ void __launch_bounds__(256)
+convert_kernel(const void* src, int sdt, void* dst, int ddt, size_t n) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i < n; i += stride) {
+        const float v = sdt == VC_F32 ? reinterpret_cast<const float*>(src)[i]
+                                      : (float)reinterpret_cast<const __bf16*>(src)[i];
+        if (ddt == VC_F32) reinterpret_cast<float*>(dst)[i] = v;
+        else reinterpret_cast<__bf16*>(dst)[i] = (__bf16)v;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw, int32_t w_dtype, int32_t n_seq,
+                 int32_t T, int32_t H, void* d_out, int32_t out_dtype, void* stream) {
+    VC_REQUIRE(d_xproj && d_Wh_fw && d_Wh_bw && d_out, "NULL argument");
+    VC_REQUIRE(n_seq > 0 && T > 0 && H > 0 && H <= 1024, "bad shape n_seq=%d T=%d H=%d", n_seq, T, H);
+    VC_REQUIRE(w_dtype == VC_F32 || w_dtype == VC_BF16, "bad w_dtype %d", w_dtype);
+    VC_REQUIRE(out_dtype == VC_F32 || out_dtype == VC_BF16, "bad out_dtype %d", out_dtype);
+    GruArgs a;
+    a.xproj = d_xproj; a.Wh[0] = d_Wh_fw; a.Wh[1] = d_Wh_bw; a.out = d_out;
+    a.n_seq = n_seq; a.T = T; a.H = H; a.out_bf16 = out_dtype == VC_BF16;
+    const size_t wbytes = (size_t)H * 3 * H * (w_dtype == VC_F32 ? 4 : 2);
+    const size_t base = 3 * (size_t)H * 4;
+    a.w_in_lds = (base + wbytes <= 150 * 1024);
+    const size_t lds = base + (a.w_in_lds ? wbytes : 0);
+    int nt = 256;
+    while (nt < 512 && nt < 2 * H) nt *= 2;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(n_seq, 2);
+    if (w_dtype == VC_F32) {
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_generic_kernel<float>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gru_generic_kernel<float>, grid, dim3(nt), lds, st, a);
+    } else {
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_generic_kernel<__bf16>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(gru_generic_kernel<__bf16>, grid, dim3(nt), lds, st, a);
+    }
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_softmax_argmax(const float* d_logits, int32_t M, int32_t N, int32_t ldl, void* d_prob, int32_t ldp,
+                      int32_t out_dtype, int32_t* d_class, void* stream) {
+    VC_REQUIRE(d_logits && d_prob, "NULL argument");
+    VC_REQUIRE(M > 0 && N > 0 && ldl >= N && ldp >= N, "bad shape M=%d N=%d ldl=%d ldp=%d", M, N, ldl, ldp);
+    VC_REQUIRE(out_dtype == VC_F32 || out_dtype == VC_BF16, "bad out_dtype %d", out_dtype);
+    hipLaunchKernelGGL(softmax_argmax_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       d_logits, M, N, ldl, d_prob, ldp, out_dtype == VC_BF16, d_class);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_convert(const void* d_src, int32_t src_dtype, void* d_dst, int32_t dst_dtype, size_t n, void* stream) {
+    VC_REQUIRE(d_src && d_dst, "NULL argument");
+    VC_REQUIRE((src_dtype == VC_F32 || src_dtype == VC_BF16) && (dst_dtype == VC_F32 || dst_dtype == VC_BF16), "bad dtype");
+    if (n == 0) return VC_OK;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(convert_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), d_src, src_dtype,
+                       d_dst, dst_dtype, n);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,229 @@
+"""Phoneme-posterior encoder with the reference's ``encoder.encoder_spec_phn`` surface.
+
+Mirrors /root/reference/encoder.py:15-388: ``encoder_spec_phn(cfg_d, ds)`` builds
+prenet -> CBHG -> dense(n_output) -> softmax/argmax (encoder.py:78-123) from the same flat
+config dict (hp/encoder_cfg_d.json keys) and exposes ``restore / save / predict / run /
+get_input / get_outputs / eval_acc``.  The TensorFlow session is replaced by eager HIP kernel
+launches (modules.py); TF checkpoints are read/written by tf_bundle.py, so ``restore()`` loads
+the reference's own ``enc_14_ckpt``.
+
+Differences a caller can see (documented, deliberate):
+  * ``inputs``, ``y_pred`` ... are light-weight handles (there is no graph); ``run(var, feed_dict)``
+    evaluates the handles this class defines.
+  * optional config key ``compute_dtype`` ('float32' default | 'bfloat16').
+  * the encoder's own training loop (``train``/``exec_train_step``, encoder.py:256-356) is a
+    "next" row of SURVEY.md section 8f and raises NotImplementedError for now.
+"""
+import os
+import sys
+from collections import namedtuple
+
+import numpy as np
+
+import modules
+import tf_bundle
+from modules import prenet, CBHG
+from aux_func import *      # noqa: F401,F403  (reference does the same: load_cfg_d, save_cfg_d ...)
+
+
+class Handle:
+    """Stand-in for a tf.Tensor / tf.placeholder attribute of the reference's model objects."""
+
+    def __init__(self, name, shape, dtype='float32'):
+        self.name, self.shape, self.dtype = name, tuple(shape), dtype
+
+    def __repr__(self):
+        return '<Handle {} shape={} dtype={}>'.format(self.name, self.shape, self.dtype)
+
+
+class encoder_spec_phn:
+    def __init__(self, cfg_d={}, ds=None, store=None):
+        self.cfg_d = cfg_d
+        self.ds = ds
+
+        self.i_global_step = 0
+        self.i_epoch = 0
+        self.summary_v = []
+
+        self.store = store if store is not None else modules.VariableStore(
+            cfg_d.get('compute_dtype', 'float32'),
+            device=cfg_d.get('device', 'cuda'))
+        self.sess = self.store                       # shared with a decoder, like the TF session
+
+        self._build_model(input_shape=self.cfg_d['input_shape'],
+                          n_output=self.cfg_d['n_output'],
+                          embed_size=self.cfg_d['embed_size'],
+                          num_conv_banks=self.cfg_d['num_conv_banks'],
+                          num_highwaynet_blocks=self.cfg_d['num_highwaynet_blocks'],
+                          dropout_rate=self.cfg_d['dropout_rate'],
+                          is_training=self.cfg_d['is_training'],
+                          scope=self.cfg_d['model_name'],
+                          use_Cudnn=self.cfg_d['use_Cudnn'],
+                          use_lstm=self.cfg_d['use_lstm'])
+
+        # optimizer state variables exist in every encoder checkpoint (encoder.py:162-169)
+        self.opt_state = {'opt/learning_rate': np.float32(cfg_d.get('learning_rate', 1e-3)),
+                          'opt/learning_rate_start': np.float32(cfg_d.get('learning_rate', 1e-3)),
+                          'opt/learning_rate_decay': np.float32(cfg_d.get('decay', 0.0)),
+                          'opt/global_step': np.int32(0), 'opt/epoch': np.int32(0)}
+        return None
+
+    # --------------------------------------------------------------------------- model
+    def _build_model(self, input_shape=(800, 256), n_output=48, embed_size=None, num_conv_banks=16,
+                     num_highwaynet_blocks=4, dropout_rate=0.5, is_training=True, scope="model",
+                     use_Cudnn=False, use_lstm=False, reuse=None):
+        """encoder.py:78-123: creates the variables (TF names) and the attribute handles."""
+        if embed_size is None:
+            embed_size = input_shape[-1]
+        if use_lstm:
+            raise NotImplementedError(' - ERROR, use_lstm is not supported (no shipped configuration uses it)')
+        self._embed_size = embed_size
+        self._scope = scope
+        modules.create_stage_variables(self.store, scope, input_shape[-1], embed_size, num_conv_banks,
+                                       num_highwaynet_blocks, n_output)
+        T = input_shape[0]
+        self.inputs = Handle(scope + '/inputs', (None,) + tuple(input_shape))
+        self.target = Handle(scope + '/target', (None, T, n_output))
+        self.CBHG_out = Handle(scope + '/CBHG_out', (None, T, embed_size))
+        self.y_logits = Handle(scope + '/y_logits', (None, T, n_output))
+        self.y_pred = Handle(scope + '/y_pred', (None, T, n_output))
+        self.y_pred_class = Handle(scope + '/y_pred_class', (None, T), 'int32')
+        return None
+
+    def get_input(self):
+        return self.inputs
+
+    def get_outputs(self):
+        output_nt = namedtuple('output_nt', 'y_pred y_pred_class y_logits CBHG_out')
+        return output_nt(self.y_pred, self.y_pred_class, self.y_logits, self.CBHG_out)
+
+    def _to_device(self, x):
+        import torch
+        if not torch.is_tensor(x):
+            x = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        x = x.to(self.store.device, dtype=torch.float32)
+        exp = tuple(self.cfg_d['input_shape'])
+        if x.dim() != 3 or tuple(x.shape[1:]) != exp:
+            raise ValueError(' - ERROR, encoder input must be [N, {}, {}], got {}'.format(exp[0], exp[1], tuple(x.shape)))
+        return x.contiguous()
+
+    def forward(self, x, ppg_pad_to=None, ppg_dtype=None):
+        """Device forward of encoder.py:101-111.  x: float32 [N, T, C] device tensor.
+        Returns dict(CBHG_out, y_logits (f32), y_pred (f32), y_pred_class (int32) and, when
+        ``ppg_pad_to`` is given, 'ppg': the posteriors zero-padded to that width in ``ppg_dtype``
+        -- the decoder's input layout)."""
+        import torch
+        c = self.cfg_d
+        if c['is_training']:
+            raise NotImplementedError(' - ERROR, encoder training mode is not built yet (SURVEY.md section 8f)')
+        st = self.store
+        with modules.variable_store(st), modules.variable_scope(self._scope):
+            xin = modules.convert(x, st.dtype)
+            prenet_out = prenet(xin, None, self._embed_size, c['dropout_rate'], False, scope="prenet")
+            cbhg_out = CBHG(prenet_out, self._embed_size, c['num_conv_banks'], c['num_highwaynet_blocks'],
+                            c['dropout_rate'], False, scope="CBHG", use_Cudnn=c['use_Cudnn'], use_lstm=c['use_lstm'])
+            y_logits = modules.dense(cbhg_out, c['n_output'], None, name="y_logits", out_f32=True)
+        y_pred, y_cls = modules.softmax_argmax(y_logits)
+        out = {'CBHG_out': cbhg_out, 'y_logits': y_logits, 'y_pred': y_pred, 'y_pred_class': y_cls}
+        if ppg_pad_to is not None:
+            if ppg_pad_to == c['n_output'] and (ppg_dtype is None or ppg_dtype == torch.float32):
+                out['ppg'] = y_pred
+            else:
+                out['ppg'] = modules.softmax_argmax(y_logits, pad_to=ppg_pad_to, out_dtype=ppg_dtype)[0]
+        return out
+
+    # --------------------------------------------------------------------------- checkpoints
+    def _all_variables(self):
+        d = self.store.to_numpy()
+        d.update(self.opt_state)
+        return d
+
+    def save(self, save_path=None, i_checkpoint=None, verbose=True):
+        """encoder.py:223-235: ``{model_path}/{model_name}-{step}`` in TF bundle format."""
+        if save_path is None:
+            save_path = '{}/{}'.format(self.cfg_d['model_path'], self.cfg_d['model_name'])
+        if i_checkpoint is None:
+            i_checkpoint = self.i_global_step
+        prefix = '{}-{}'.format(save_path, int(i_checkpoint))
+        tf_bundle.write_bundle(prefix, self._all_variables())
+        tf_bundle.update_checkpoint_state(os.path.dirname(prefix) or '.', os.path.basename(prefix))
+        if verbose:
+            print(' Saved: "{}"'.format(prefix))
+        return None
+
+    def restore(self, save_path=None, i_checkpoint=None):
+        """encoder.py:238-253: latest checkpoint of cfg_d['model_path'] (or an explicit step /
+        prefix); on failure prints to stderr and exits with status 1, like the reference."""
+        if save_path is None:
+            if i_checkpoint is None:
+                save_path = tf_bundle.latest_checkpoint(self.cfg_d['model_path'])
+            else:
+                save_path = '{}/{}-{}'.format(self.cfg_d['model_path'], self.cfg_d['model_name'], int(i_checkpoint))
+        try:
+            names = set(n for n in self.store.vars if n.startswith(self._scope + '/')) | set(self.opt_state)
+            w = tf_bundle.read_bundle(save_path, verify_crc=True, names=names)
+            self.store.load_dict({k: v for k, v in w.items() if k in self.store.vars}, strict=False)
+            missing = [n for n in self.store.vars if n.startswith(self._scope + '/') and n not in w]
+            if missing:
+                raise KeyError(missing[:3])
+            for k in self.opt_state:
+                if k in w:
+                    self.opt_state[k] = w[k]
+            self.i_global_step = int(self.opt_state['opt/global_step'])
+            self.i_epoch = int(self.opt_state['opt/epoch'])
+            print('Restored: "{}"'.format(save_path))
+        except Exception:
+            print(' Model not found: {}'.format(save_path), file=sys.stderr)
+            sys.exit(1)
+        return None
+
+    # --------------------------------------------------------------------------- run API
+    def predict(self, x, batch_size=32):
+        """encoder.py:359-367: softmax posteriors [N, T, n_output] (numpy float32), evaluated in
+        chunks of ``batch_size`` windows."""
+        y_pred_v = []
+        for i_s in range(0, x.shape[0], batch_size):
+            x_batch = self._to_device(x[i_s:min(i_s + batch_size, x.shape[0])])
+            y_pred_v.append(self.forward(x_batch)['y_pred'].cpu().numpy())
+        return np.concatenate(y_pred_v, axis=0)
+
+    def run(self, var, feed_dict={}):
+        """encoder.py:370-371: evaluate one handle or a list of handles given {inputs: x}."""
+        single = not isinstance(var, (list, tuple))
+        vs = [var] if single else list(var)
+        if self.inputs not in feed_dict:
+            raise Exception(' - ERROR, run: feed_dict must provide encoder.inputs')
+        out = self.forward(self._to_device(feed_dict[self.inputs]))
+        res = []
+        for v in vs:
+            key = v.name.split('/')[-1]
+            if key not in out:
+                raise Exception(' - ERROR, run: {} cannot be evaluated'.format(v))
+            res.append(out[key].float().cpu().numpy() if key != 'y_pred_class' else out[key].cpu().numpy())
+        return res[0] if single else res
+
+    def eval_acc(self, ds_sampler, n_batchs=100):
+        """encoder.py:374-388."""
+        n_c = 0
+        n_t = 0
+        acc = 0.0
+        for i_batch, (mfcc_batch, phn_v_batch) in enumerate(ds_sampler):
+            y_pred = self.run(self.y_pred, {self.inputs: mfcc_batch})
+            y_dec = np.argmax(y_pred, axis=-1)
+            y_true = np.argmax(phn_v_batch, axis=-1)
+            n_c += (y_dec == y_true).sum()
+            n_t += y_dec.size
+            acc = n_c / n_t
+            print('acc[{:4d}] = {:5.03f}'.format(int(n_t), acc))
+        return acc, n_t
+
+    def exec_train_step(self, inputs, target):
+        raise NotImplementedError(' - ERROR, encoder training is a "next" row (SURVEY.md section 8f)')
+
+    def exec_calc_metrics(self, inputs, target, summary_mode='validation'):
+        raise NotImplementedError(' - ERROR, encoder training is a "next" row (SURVEY.md section 8f)')
+
+    def train(self):
+        if not self.cfg_d['is_training']:
+            raise Exception('Model is not in training model')
+        raise NotImplementedError(' - ERROR, encoder training is a "next" row (SURVEY.md section 8f)')

@@ -1,0 +1,521 @@
+"""Network building blocks with the reference's ``modules`` surface, run on the MI355X.
+
+Mirrors /root/reference/modules.py:39-356 -- same function names and leading argument order
+(``bn``, ``conv1d``, ``conv1d_banks``, ``gru``, ``prenet``, ``highwaynet``, ``CBHG``) -- but
+eager: every function takes/returns a ``torch.cuda`` tensor of shape [N, T, C] and launches
+hand-written HIP kernels through the C ABI (include/vc_hip.h: ``vc_conv_gemm``,
+``vc_gru_bidir``).  torch only owns device memory and does one-time weight re-layout.
+
+TensorFlow's ``variable_scope`` / ``get_variable`` pair is replaced by a tiny equivalent:
+a ``VariableStore`` (name -> float32 master tensor in TF layout, names identical to the
+reference's checkpoints) and a scope stack (``variable_scope``).  Kernel-format copies
+(transposed kernels, folded BatchNorm, packed GRU weights, optional bf16) are derived lazily
+and cached; ``VariableStore.invalidate()`` drops them after a weight update.
+
+``embed`` and ``attention_decoder`` (modules.py:10-36, 246-272) are dead code in the reference
+(never called) and are not provided; ``lstm`` (modules.py:207-243) is reachable only with
+``use_lstm`` true, which no shipped configuration sets -> ``CBHG(use_lstm=True)`` raises.
+"""
+import contextlib
+import ctypes as C
+import math
+import threading
+
+import numpy as np
+
+import _vc
+
+BN_EPS = 1e-3           # tf.contrib.layers.batch_norm epsilon (read from the reference's .meta)
+BN_DECAY = 0.999        # moving-average decay
+BANK_FILTERS = 128      # conv1d_banks is called without embed_size (modules.py:328) => 256 // 2
+
+
+def _torch():
+    import torch
+    return torch
+
+
+# ------------------------------------------------------------------------------- variables
+class VariableStore:
+    """Named float32 master variables (TF layout) + cached kernel-format derivatives."""
+
+    def __init__(self, compute_dtype='float32', device='cuda', seed=0):
+        torch = _torch()
+        if compute_dtype in ('float32', 'f32', torch.float32):
+            self.dtype, self.vc_dtype = torch.float32, _vc.VC_F32
+        elif compute_dtype in ('bfloat16', 'bf16', torch.bfloat16):
+            self.dtype, self.vc_dtype = torch.bfloat16, _vc.VC_BF16
+        else:
+            raise ValueError(' - ERROR, compute_dtype {} not understood'.format(compute_dtype))
+        self.device = torch.device(device)
+        self.vars = {}
+        self.order = []                      # creation order (== TF graph order)
+        self.non_trainable = set()
+        self._cache = {}
+        self._rng = np.random.RandomState(seed)
+
+    # -- creation (tf.get_variable with the layer's default initializer)
+    def get(self, name, shape, init):
+        v = self.vars.get(name)
+        if v is not None:
+            if tuple(v.shape) != tuple(shape):
+                raise ValueError(' - ERROR, variable {} has shape {}, requested {}'.format(name, tuple(v.shape), shape))
+            return v
+        torch = _torch()
+        if init == 'glorot':
+            if len(shape) == 2:
+                fan_in, fan_out = shape
+            else:
+                rf = int(np.prod(shape[:-2]))
+                fan_in, fan_out = shape[-2] * rf, shape[-1] * rf
+            lim = math.sqrt(6.0 / (fan_in + fan_out))
+            a = self._rng.uniform(-lim, lim, size=shape).astype(np.float32)
+        elif isinstance(init, (int, float)):
+            a = np.full(shape, float(init), dtype=np.float32)
+        else:
+            raise ValueError(init)
+        v = torch.from_numpy(a).to(self.device)
+        self.vars[name] = v
+        self.order.append(name)
+        if name.endswith('/moving_mean') or name.endswith('/moving_variance'):
+            self.non_trainable.add(name)
+        return v
+
+    def assign(self, name, value):
+        torch = _torch()
+        t = value if torch.is_tensor(value) else torch.from_numpy(np.ascontiguousarray(value, dtype=np.float32))
+        if name not in self.vars:
+            raise KeyError(name)
+        if tuple(t.shape) != tuple(self.vars[name].shape):
+            raise ValueError(' - ERROR, assign {}: shape {} != {}'.format(name, tuple(t.shape), tuple(self.vars[name].shape)))
+        self.vars[name].copy_(t.to(self.device, dtype=torch.float32))
+        self.invalidate()
+
+    def load_dict(self, d, strict=True):
+        """Copy every variable this store knows from ``d`` (name -> array)."""
+        missing = [n for n in self.vars if n not in d]
+        if strict and missing:
+            raise KeyError('variables missing from checkpoint: {}'.format(missing[:4]))
+        torch = _torch()
+        for n, v in self.vars.items():
+            if n in d:
+                a = np.ascontiguousarray(d[n], dtype=np.float32)
+                if tuple(a.shape) != tuple(v.shape):
+                    raise ValueError(' - ERROR, checkpoint tensor {} has shape {}, model wants {}'.format(n, a.shape, tuple(v.shape)))
+                v.copy_(torch.from_numpy(a))
+        self.invalidate()
+
+    def to_numpy(self):
+        return {n: v.detach().cpu().numpy() for n, v in self.vars.items()}
+
+    def trainable_names(self, prefix=''):
+        return [n for n in self.order if n.startswith(prefix) and n not in self.non_trainable]
+
+    def invalidate(self):
+        self._cache.clear()
+
+    def cached(self, key, fn):
+        v = self._cache.get(key)
+        if v is None:
+            v = fn()
+            self._cache[key] = v
+        return v
+
+
+_CTX = threading.local()
+
+
+def _ctx():
+    if not hasattr(_CTX, 'stack'):
+        _CTX.stack = []
+        _CTX.store = None
+    return _CTX
+
+
+@contextlib.contextmanager
+def variable_store(store):
+    """Make ``store`` the current variable store (the stand-in for the TF default graph)."""
+    c = _ctx()
+    prev = c.store
+    c.store = store
+    try:
+        yield store
+    finally:
+        c.store = prev
+
+
+@contextlib.contextmanager
+def variable_scope(name, reuse=None):
+    """tf.variable_scope: pushes ``name`` on the scope stack."""
+    c = _ctx()
+    c.stack.append(name)
+    try:
+        yield '/'.join(c.stack)
+    finally:
+        c.stack.pop()
+
+
+def _scope(*names):
+    return '/'.join(list(_ctx().stack) + [n for n in names if n])
+
+
+def _store():
+    s = _ctx().store
+    if s is None:
+        raise RuntimeError(' - ERROR, no current VariableStore (use `with variable_store(store):`)')
+    return s
+
+
+# ------------------------------------------------------------------------------- launch helpers
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _as3(x):
+    if x.dim() != 3:
+        raise ValueError(' - ERROR, expected a [N, T, C] tensor, got shape {}'.format(tuple(x.shape)))
+    return x
+
+
+def gemm_launch(X, M, T, Cin, ldx, N, groups, Cout, ldc, vc_dtype, mode=_vc.GEMM_PLAIN,
+                pro_scale=None, pro_shift=None, pro_relu=0, pro_pool=0,
+                epi_scale=None, epi_shift=None, act=_vc.ACT_NONE, R=None, ldr=0, out_f32=False):
+    """Fill a vc_gemm_desc and launch vc_conv_gemm on the current stream.
+    groups: list of (Bt tensor [N, K], K, taps, pad_l, c_off)."""
+    d = _vc.GemmDesc()
+    d.dtype, d.mode = vc_dtype, mode
+    d.d_X = X.data_ptr()
+    d.M, d.T, d.Cin, d.ldx, d.N, d.n_groups = M, T, Cin, ldx, N, len(groups)
+    for i, (Bt, K, taps, pad_l, c_off) in enumerate(groups):
+        g = d.groups[i]
+        g.d_Bt, g.K, g.taps, g.pad_l, g.c_off = Bt.data_ptr(), K, taps, pad_l, c_off
+    d.d_pro_scale = pro_scale.data_ptr() if pro_scale is not None else None
+    d.d_pro_shift = pro_shift.data_ptr() if pro_shift is not None else None
+    d.pro_relu, d.pro_pool = int(pro_relu), int(pro_pool)
+    d.d_epi_scale = epi_scale.data_ptr() if epi_scale is not None else None
+    d.d_epi_shift = epi_shift.data_ptr() if epi_shift is not None else None
+    d.act = act
+    d.d_R = R.data_ptr() if R is not None else None
+    d.ldr = ldr
+    d.d_C, d.ldc, d.out_f32 = Cout.data_ptr(), ldc, int(bool(out_f32))
+    _vc.check(_vc.lib().vc_conv_gemm(C.byref(d), _vc.current_stream()))
+    return Cout
+
+
+def convert(x, dtype):
+    """dtype conversion through vc_convert (f32 <-> bf16)."""
+    torch = _torch()
+    if x.dtype == dtype:
+        return x
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    code = {torch.float32: _vc.VC_F32, torch.bfloat16: _vc.VC_BF16}
+    _vc.check(_vc.lib().vc_convert(x.data_ptr(), code[x.dtype], y.data_ptr(), code[dtype], x.numel(),
+                                   _vc.current_stream()))
+    return y
+
+
+# ------------------------------------------------------------------------------- weight prep
+def _prep_dense(store, scope, cin, units, bias_init=0.0):
+    k = store.get(scope + '/kernel', (cin, units), 'glorot')
+    b = store.get(scope + '/bias', (units,), bias_init)
+
+    def build():
+        torch = _torch()
+        cp = _pad8(cin)
+        bt = torch.zeros((units, cp), dtype=torch.float32, device=store.device)
+        bt[:, :cin] = k.t()
+        return bt.to(store.dtype).contiguous(), b.clone()
+    return store.cached(('dense', scope), build)
+
+
+def _prep_conv(store, scope, size, cin, filters):
+    k = store.get(scope + '/conv1d/kernel', (size, cin, filters), 'glorot')
+
+    def build():
+        return k.reshape(size * cin, filters).t().contiguous().to(store.dtype)
+    return store.cached(('conv', scope), build)
+
+
+def _bn_vars(store, scope, C_):
+    return (store.get(scope + '/beta', (C_,), 0.0), store.get(scope + '/gamma', (C_,), 1.0),
+            store.get(scope + '/moving_mean', (C_,), 0.0), store.get(scope + '/moving_variance', (C_,), 1.0))
+
+
+def _prep_bn(store, scope, C_):
+    beta, gamma, mean, var = _bn_vars(store, scope, C_)
+
+    def build():
+        torch = _torch()
+        s = gamma * torch.rsqrt(var + BN_EPS)
+        return s.contiguous(), (beta - mean * s).contiguous()
+    return store.cached(('bn', scope), build)
+
+
+def _prep_highway(store, scope, H):
+    k1 = store.get(scope + '/dense1/kernel', (H, H), 'glorot')
+    b1 = store.get(scope + '/dense1/bias', (H,), 0.0)
+    k2 = store.get(scope + '/dense2/kernel', (H, H), 'glorot')
+    b2 = store.get(scope + '/dense2/bias', (H,), -1.0)
+
+    def build():
+        torch = _torch()
+        nb = (H + 31) // 32
+        bt = torch.zeros((64 * nb, H), dtype=torch.float32, device=store.device)
+        bias = torch.zeros((64 * nb,), dtype=torch.float32, device=store.device)
+        for q in range(nb):
+            lo, hi = 32 * q, min(H, 32 * q + 32)
+            bt[64 * q:64 * q + (hi - lo)] = k1[:, lo:hi].t()
+            bt[64 * q + 32:64 * q + 32 + (hi - lo)] = k2[:, lo:hi].t()
+            bias[64 * q:64 * q + (hi - lo)] = b1[lo:hi]
+            bias[64 * q + 32:64 * q + 32 + (hi - lo)] = b2[lo:hi]
+        return bt.to(store.dtype).contiguous(), bias
+    return store.cached(('highway', scope), build)
+
+
+def _prep_gru(store, scope, cin, H):
+    w = {}
+    for d in ('fw', 'bw'):
+        s = '{}/bidirectional_rnn/{}/gru_cell'.format(scope, d)
+        w[d] = (store.get(s + '/gates/kernel', (cin + H, 2 * H), 'glorot'),
+                store.get(s + '/gates/bias', (2 * H,), 1.0),
+                store.get(s + '/candidate/kernel', (cin + H, H), 'glorot'),
+                store.get(s + '/candidate/bias', (H,), 0.0))
+
+    def build():
+        torch = _torch()
+        btx = torch.cat([torch.cat([w[d][0][:cin].t(), w[d][2][:cin].t()], 0) for d in ('fw', 'bw')], 0)
+        bx = torch.cat([torch.cat([w[d][1], w[d][3]], 0) for d in ('fw', 'bw')], 0)
+        wh = [torch.cat([w[d][0][cin:], w[d][2][cin:]], 1).contiguous().to(store.dtype) for d in ('fw', 'bw')]
+        return btx.contiguous().to(store.dtype), bx.contiguous(), wh[0], wh[1]
+    return store.cached(('gru', scope), build)
+
+
+# ------------------------------------------------------------------------------- blocks
+def dense(inputs, units, activation_fn=None, name='dense', bias_init=0.0, out_f32=False, in_features=None):
+    """tf.layers.dense(inputs, units, activation, name=name) on [N, T, C] (modules.py:291-293).
+    ``in_features``: true input width when ``inputs`` carries zero padding columns up to a
+    multiple of 8 (the 61-class posteriors are stored 64 wide)."""
+    torch = _torch()
+    store = _store()
+    x = _as3(inputs)
+    N_, T_, Cx = x.shape
+    scope = _scope(name)
+    cin = Cx if in_features is None else in_features
+    kname = scope + '/kernel'
+    if kname in store.vars:
+        cin = store.vars[kname].shape[0]
+    bt, b = _prep_dense(store, scope, cin, units, bias_init)
+    if Cx != _pad8(cin):
+        raise ValueError(' - ERROR, dense {}: input width {} does not match kernel rows {}'.format(scope, Cx, cin))
+    out = torch.empty((N_, T_, units), dtype=torch.float32 if out_f32 else store.dtype, device=x.device)
+    act = {None: _vc.ACT_NONE, 'relu': _vc.ACT_RELU, 'sigmoid': _vc.ACT_SIGMOID, 'tanh': _vc.ACT_TANH}[activation_fn]
+    gemm_launch(x, N_ * T_, T_, Cx, Cx, units, [(bt, Cx, 1, 0, 0)], out, units, store.vc_dtype,
+                epi_shift=b, act=act, out_f32=out_f32)
+    return out
+
+
+def bn(inputs, is_training=True, activation_fn=None, scope="bn", reuse=None):
+    """modules.py:39-102 in inference mode as a stand-alone op: the folded scale/shift is run
+    through the GEMM kernel's epilogue with an identity kernel only in tests; the hot path
+    never calls this -- conv1d()/conv1d_banks() fuse the normalisation (see CBHG)."""
+    if is_training:
+        raise NotImplementedError(' - ERROR, bn: training-mode batch statistics are fused into the training step')
+    torch = _torch()
+    store = _store()
+    x = _as3(inputs)
+    N_, T_, C_ = x.shape
+    s, sh = _prep_bn(store, _scope(scope), C_)
+    eye = store.cached(('eye', C_), lambda: torch.eye(C_, dtype=store.dtype, device=store.device))
+    out = torch.empty_like(x)
+    act = {None: _vc.ACT_NONE, 'relu': _vc.ACT_RELU}[activation_fn]
+    gemm_launch(x, N_ * T_, T_, C_, C_, C_, [(eye, C_, 1, 0, 0)], out, C_, store.vc_dtype,
+                epi_scale=s, epi_shift=sh, act=act)
+    return out
+
+
+def conv1d(inputs, filters=None, size=1, rate=1, padding="SAME", use_bias=False, activation_fn=None,
+           scope="conv1d", reuse=None, bn_scope=None, residual=None, pool_input=False):
+    """modules.py:104-140 (tf.layers.conv1d, stride 1, no bias).  Extra keyword arguments fuse
+    what the reference applies right after/before the convolution inside CBHG:
+      bn_scope    inference batch norm of that scope folded into the epilogue (modules.py:335,338)
+      activation_fn 'relu' after the norm
+      residual    tensor added after the norm (modules.py:340)
+      pool_input  max_pooling1d(2, 1, 'same') applied to ``inputs`` on the fly (modules.py:331)"""
+    if rate != 1 or padding.upper() != "SAME" or use_bias:
+        raise NotImplementedError(' - ERROR, conv1d: only rate=1, padding=SAME, use_bias=False are used by the reference')
+    torch = _torch()
+    store = _store()
+    x = _as3(inputs)
+    N_, T_, Cin = x.shape
+    if filters is None:
+        filters = Cin
+    with variable_scope(scope):
+        bt = _prep_conv(store, _scope(), size, Cin, filters)
+    s = sh = None
+    if bn_scope is not None:
+        s, sh = _prep_bn(store, _scope(bn_scope), filters)
+    out = torch.empty((N_, T_, filters), dtype=store.dtype, device=x.device)
+    act = {None: _vc.ACT_NONE, 'relu': _vc.ACT_RELU}[activation_fn]
+    gemm_launch(x, N_ * T_, T_, Cin, Cin, filters, [(bt, size * Cin, size, (size - 1) // 2, 0)], out, filters,
+                store.vc_dtype, pro_pool=pool_input, epi_scale=s, epi_shift=sh, act=act,
+                R=residual, ldr=filters if residual is not None else 0)
+    return out
+
+
+def conv1d_banks(inputs, K=16, embed_size=256, is_training=True, scope="conv1d_banks", reuse=None):
+    """modules.py:144-166: K convolutions of width 1..K (embed_size//2 filters each), concat,
+    batch norm, relu -- ONE grouped launch, heaviest bank first, norm+relu in the epilogue."""
+    if is_training:
+        raise NotImplementedError(' - ERROR, conv1d_banks: training mode runs through the fused training step')
+    torch = _torch()
+    store = _store()
+    x = _as3(inputs)
+    N_, T_, Cin = x.shape
+    F_ = embed_size // 2
+    if K > _vc.GEMM_MAX_GROUPS:
+        raise ValueError(' - ERROR, conv1d_banks: K={} > {}'.format(K, _vc.GEMM_MAX_GROUPS))
+    groups = []
+    with variable_scope(scope):
+        for k in range(1, K + 1):
+            sub = 'conv1d' if k == 1 else 'num_{}/conv1d'.format(k)
+            with variable_scope(sub):
+                bt = _prep_conv(store, _scope(), k, Cin, F_)
+            groups.append((bt, k * Cin, k, (k - 1) // 2, F_ * (k - 1)))
+        s, sh = _prep_bn(store, _scope('bn'), F_ * K)
+    out = torch.empty((N_, T_, F_ * K), dtype=store.dtype, device=x.device)
+    gemm_launch(x, N_ * T_, T_, Cin, Cin, F_, groups, out, F_ * K, store.vc_dtype,
+                epi_scale=s, epi_shift=sh, act=_vc.ACT_RELU)
+    return out
+
+
+def gru(inputs, num_units=None, bidirection=False, scope="gru", use_Cudnn=False, reuse=None):
+    """modules.py:168-204 with bidirection=True (the only form CBHG uses): the x-halves of both
+    directions' cell matmuls are one GEMM, the recurrence one persistent launch."""
+    if not bidirection:
+        raise NotImplementedError(' - ERROR, gru: the reference only instantiates the bidirectional form')
+    torch = _torch()
+    store = _store()
+    x = _as3(inputs)
+    N_, T_, Cin = x.shape
+    H = Cin if num_units is None else num_units
+    btx, bx, wh_fw, wh_bw = _prep_gru(store, _scope(scope), Cin, H)
+    xproj = torch.empty((N_ * T_, 6 * H), dtype=torch.float32, device=x.device)
+    gemm_launch(x, N_ * T_, T_, Cin, Cin, 6 * H, [(btx, Cin, 1, 0, 0)], xproj, 6 * H, store.vc_dtype,
+                epi_shift=bx, out_f32=True)
+    out = torch.empty((N_, T_, 2 * H), dtype=store.dtype, device=x.device)
+    _vc.check(_vc.lib().vc_gru_bidir(xproj.data_ptr(), wh_fw.data_ptr(), wh_bw.data_ptr(), store.vc_dtype,
+                                     N_, T_, H, out.data_ptr(), store.vc_dtype, _vc.current_stream()))
+    return out
+
+
+def lstm(inputs, num_units=None, bidirection=False, scope="lstm", use_Cudnn=False, reuse=None):
+    raise NotImplementedError(' - ERROR, lstm: no shipped configuration sets use_lstm (modules.py:207-243)')
+
+
+def _dropout(x, rate, is_training):
+    if is_training:
+        raise NotImplementedError(' - ERROR, dropout in training mode runs through the fused training step')
+    return x
+
+
+def prenet(inputs, num_units=None, embed_size=256, dropout_rate=0.5, is_training=True, scope="prenet", reuse=None,
+           in_features=None):
+    """modules.py:274-295: dense(E)+relu, dropout, dense(E/2)+relu, dropout."""
+    if num_units is None:
+        num_units = [embed_size, embed_size // 2]
+    with variable_scope(scope):
+        outputs = dense(inputs, num_units[0], 'relu', name="dense1", in_features=in_features)
+        outputs = _dropout(outputs, dropout_rate, is_training)
+        outputs = dense(outputs, num_units[1], 'relu', name="dense2")
+        outputs = _dropout(outputs, dropout_rate, is_training)
+    return outputs
+
+
+def highwaynet(inputs, num_units=None, scope="highwaynet", reuse=None):
+    """modules.py:297-319: H = relu(x W1 + b1), T = sigmoid(x W2 + b2), out = H*T + x*(1-T);
+    both matmuls and the gate are one launch (paired-column epilogue)."""
+    torch = _torch()
+    store = _store()
+    x = _as3(inputs)
+    N_, T_, Cx = x.shape
+    if not num_units:
+        num_units = Cx
+    if num_units != Cx:
+        raise ValueError(' - ERROR, highwaynet: num_units must equal the input width')
+    bt, bias = _prep_highway(store, _scope(scope), Cx)
+    out = torch.empty_like(x)
+    gemm_launch(x, N_ * T_, T_, Cx, Cx, bt.shape[0], [(bt, Cx, 1, 0, 0)], out, Cx, store.vc_dtype,
+                mode=_vc.GEMM_HIGHWAY, epi_shift=bias)
+    return out
+
+
+def CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dropout_rate=0.5, is_training=True,
+         scope="CBHG", use_Cudnn=False, use_lstm=False, reuse=None):
+    """modules.py:323-356.  [N, T, E/2] -> [N, T, E]."""
+    if use_lstm:
+        raise NotImplementedError(' - ERROR, CBHG: use_lstm is not used by any shipped configuration')
+    with variable_scope(scope):
+        enc = conv1d_banks(inputs, K=num_conv_banks, is_training=is_training)              # (N, T, K*128)
+        # max pooling (modules.py:331) is fused into conv1d_1's operand load
+        enc = conv1d(enc, filters=embed_size // 2, size=3, scope="conv1d_1", bn_scope="conv1d_1",
+                     activation_fn='relu', pool_input=True)                                # (N, T, E/2)
+        enc = conv1d(enc, filters=embed_size // 2, size=3, scope="conv1d_2", bn_scope="conv1d_2",
+                     residual=inputs)                                                      # + residual
+        for i in range(num_highwaynet_blocks):
+            enc = highwaynet(enc, num_units=embed_size // 2, scope='highwaynet_{}'.format(i))
+        output = gru(enc, num_units=embed_size // 2, bidirection=True, use_Cudnn=use_Cudnn)  # (N, T, E)
+    return output
+
+
+def create_stage_variables(store, scope, in_features, embed_size, num_conv_banks, num_highwaynet_blocks, n_output):
+    """Create (if absent) every variable of one prenet -> CBHG -> dense(n_output) stage under
+    ``scope`` with TensorFlow's default initialisers, in graph order, WITHOUT launching kernels
+    (so checkpoints can be restored before the first forward).  Names as in the reference's
+    checkpoints."""
+    E, H = embed_size, embed_size // 2
+    store.get(scope + '/prenet/dense1/kernel', (in_features, E), 'glorot')
+    store.get(scope + '/prenet/dense1/bias', (E,), 0.0)
+    store.get(scope + '/prenet/dense2/kernel', (E, H), 'glorot')
+    store.get(scope + '/prenet/dense2/bias', (H,), 0.0)
+    b = scope + '/CBHG/conv1d_banks'
+    for k in range(1, num_conv_banks + 1):
+        sub = b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k))
+        store.get(sub + '/conv1d/kernel', (k, H, BANK_FILTERS), 'glorot')
+    _bn_vars(store, b + '/bn', BANK_FILTERS * num_conv_banks)
+    store.get(scope + '/CBHG/conv1d_1/conv1d/kernel', (3, BANK_FILTERS * num_conv_banks, H), 'glorot')
+    _bn_vars(store, scope + '/CBHG/conv1d_1', H)
+    store.get(scope + '/CBHG/conv1d_2/conv1d/kernel', (3, H, H), 'glorot')
+    _bn_vars(store, scope + '/CBHG/conv1d_2', H)
+    for i in range(num_highwaynet_blocks):
+        hs = scope + '/CBHG/highwaynet_{}'.format(i)
+        store.get(hs + '/dense1/kernel', (H, H), 'glorot')
+        store.get(hs + '/dense1/bias', (H,), 0.0)
+        store.get(hs + '/dense2/kernel', (H, H), 'glorot')
+        store.get(hs + '/dense2/bias', (H,), -1.0)
+    for d in ('fw', 'bw'):
+        gs = scope + '/CBHG/gru/bidirectional_rnn/{}/gru_cell'.format(d)
+        store.get(gs + '/gates/kernel', (2 * H, 2 * H), 'glorot')
+        store.get(gs + '/gates/bias', (2 * H,), 1.0)
+        store.get(gs + '/candidate/kernel', (2 * H, H), 'glorot')
+        store.get(gs + '/candidate/bias', (H,), 0.0)
+    store.get(scope + '/y_logits/kernel', (E, n_output), 'glorot')
+    store.get(scope + '/y_logits/bias', (n_output,), 0.0)
+
+
+def softmax_argmax(logits, n_valid=None, pad_to=None, out_dtype=None):
+    """tf.nn.softmax + tf.argmax over the last axis (encoder.py:110-111).  Returns
+    (prob [N, T, pad_to] with zero padding columns, class ids int32 [N, T])."""
+    torch = _torch()
+    x = _as3(logits)
+    if x.dtype != torch.float32:
+        raise ValueError(' - ERROR, softmax_argmax wants float32 logits')
+    N_, T_, W = x.shape
+    n = W if n_valid is None else n_valid
+    ldp = n if pad_to is None else pad_to
+    out_dtype = out_dtype or torch.float32
+    prob = torch.empty((N_, T_, ldp), dtype=out_dtype, device=x.device)
+    cls = torch.empty((N_, T_), dtype=torch.int32, device=x.device)
+    code = {torch.float32: _vc.VC_F32, torch.bfloat16: _vc.VC_BF16}[out_dtype]
+    _vc.check(_vc.lib().vc_softmax_argmax(x.data_ptr(), N_ * T_, n, W, prob.data_ptr(), ldp, code,
+                                          cls.data_ptr(), _vc.current_stream()))
+    return prob, cls

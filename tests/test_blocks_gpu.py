@@ -1,0 +1,173 @@
+"""Network blocks on the MI355X vs the CPU oracle (oracle/model_oracle.py, TF-1.9 semantics).
+
+Every test calls the HIP kernels through the C ABI (modules.py -> vc_conv_gemm / vc_gru_bidir /
+vc_softmax_argmax).  Tolerances: float32 path abs/rel 2e-5 against a float64 oracle (the f32
+MFMA is an exact fp32 fma chain; only the summation order differs); bf16 path 3e-2 abs on O(1)
+activations."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_oracle as mo
+
+pytestmark = pytest.mark.gpu
+
+
+def _store(dtype, wdict=None):
+    import modules
+    st = modules.VariableStore(dtype)
+    return st
+
+
+def _close(dev, ref, tol, what):
+    dev = dev.float().cpu().double()
+    ref = ref.double()
+    assert dev.shape == ref.shape, (what, dev.shape, ref.shape)
+    err = (dev - ref).abs().max().item()
+    scale = max(1.0, ref.abs().max().item())
+    assert err <= tol * scale, '%s: max abs err %.3e (scale %.2f) > %.1e' % (what, err, scale, tol)
+
+
+TOL = {'float32': 2e-5, 'bfloat16': 3e-2}
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('N,T,cin,units', [(2, 40, 80, 80), (3, 16, 40, 61), (1, 400, 256, 201), (2, 50, 64, 520)])
+def test_dense(dtype, N, T, cin, units):
+    import modules
+    rng = np.random.RandomState(0)
+    st = _store(dtype)
+    x = torch.from_numpy(rng.standard_normal((N, T, cin)).astype(np.float32))
+    with modules.variable_store(st), modules.variable_scope('m'):
+        for act in (None, 'relu', 'sigmoid'):
+            y = modules.dense(modules.convert(x.cuda(), st.dtype), units, act, name='d_%s' % act, out_f32=True)
+            w = {k: v.cpu().double() for k, v in st.vars.items()}
+            xr = x.double() if dtype == 'float32' else x.bfloat16().double()
+            ref = mo.dense(xr, w, 'm/d_%s' % act, act)
+            _close(y, ref, TOL[dtype], 'dense %s' % act)
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('size', [1, 2, 3, 4, 5, 8])
+def test_conv1d_same_padding(dtype, size):
+    """TF SAME padding incl. even kernels (left (k-1)//2, right k-1-left), no leakage across
+    windows, M / N / K tails."""
+    import modules
+    rng = np.random.RandomState(size)
+    N, T, cin, f = 3, 37, 40, 72
+    st = _store(dtype)
+    x = torch.from_numpy(rng.standard_normal((N, T, cin)).astype(np.float32))
+    with modules.variable_store(st), modules.variable_scope('c'):
+        y = modules.conv1d(modules.convert(x.cuda(), st.dtype), filters=f, size=size, scope='cv')
+    k = st.vars['c/cv/conv1d/kernel'].cpu().double()
+    xr = x.double() if dtype == 'float32' else x.bfloat16().double()
+    if dtype == 'bfloat16':
+        k = k.float().bfloat16().double()
+    _close(y, mo.conv1d(xr, k), TOL[dtype], 'conv1d k=%d' % size)
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_conv1d_fused_bn_relu_pool_residual(dtype):
+    import modules
+    rng = np.random.RandomState(3)
+    N, T, cin, f = 2, 48, 128, 40
+    st = _store(dtype)
+    x = torch.from_numpy(np.abs(rng.standard_normal((N, T, cin))).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((N, T, f)).astype(np.float32))
+    with modules.variable_store(st), modules.variable_scope('c'):
+        modules._bn_vars(st, 'c/p1', f)
+        for nm in ('beta', 'gamma', 'moving_mean', 'moving_variance'):
+            v = rng.uniform(0.5, 1.5, f) if nm in ('gamma', 'moving_variance') else rng.uniform(-0.3, 0.3, f)
+            st.assign('c/p1/' + nm, v.astype(np.float32))
+        y = modules.conv1d(modules.convert(x.cuda(), st.dtype), filters=f, size=3, scope='p1', bn_scope='p1',
+                           activation_fn='relu', pool_input=True,
+                           residual=modules.convert(res.cuda(), st.dtype))
+    w = {k: v.cpu().double() for k, v in st.vars.items()}
+    cast = (lambda t: t.double()) if dtype == 'float32' else (lambda t: t.bfloat16().double())
+    k = cast(st.vars['c/p1/conv1d/kernel'].cpu())
+    ref = torch.relu(mo.bn(mo.conv1d(mo.max_pool_2_same(cast(x)), k), w, 'c/p1')) + cast(res)
+    _close(y, ref, TOL[dtype], 'fused conv1d')
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('K,cin', [(6, 40), (5, 32), (16, 128)])
+def test_conv1d_banks(dtype, K, cin):
+    import modules
+    rng = np.random.RandomState(K)
+    N, T = 2, 56
+    st = _store(dtype)
+    x = torch.from_numpy(rng.standard_normal((N, T, cin)).astype(np.float32))
+    with modules.variable_store(st), modules.variable_scope('e'):
+        y = modules.conv1d_banks(modules.convert(x.cuda(), st.dtype), K=K, is_training=False)
+        for nm in ('beta', 'gamma', 'moving_mean', 'moving_variance'):
+            v = rng.uniform(0.5, 1.5, 128 * K) if nm in ('gamma', 'moving_variance') else rng.uniform(-0.3, 0.3, 128 * K)
+            st.assign('e/conv1d_banks/bn/' + nm, v.astype(np.float32))
+        y = modules.conv1d_banks(modules.convert(x.cuda(), st.dtype), K=K, is_training=False)
+    assert y.shape == (N, T, 128 * K)
+    cast = (lambda t: t.double()) if dtype == 'float32' else (lambda t: t.float().bfloat16().double())
+    w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
+    ref = mo.conv1d_banks(cast(x), w, 'e/conv1d_banks', K)
+    _close(y, ref, TOL[dtype], 'banks K=%d' % K)
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('H', [40, 128, 72])
+def test_highwaynet(dtype, H):
+    import modules
+    rng = np.random.RandomState(H)
+    N, T = 2, 44
+    st = _store(dtype)
+    x = torch.from_numpy(rng.standard_normal((N, T, H)).astype(np.float32))
+    with modules.variable_store(st), modules.variable_scope('h'):
+        y = modules.highwaynet(modules.convert(x.cuda(), st.dtype), num_units=H, scope='highwaynet_0')
+        st.assign('h/highwaynet_0/dense1/bias', rng.uniform(-0.2, 0.2, H).astype(np.float32))
+        y = modules.highwaynet(modules.convert(x.cuda(), st.dtype), num_units=H, scope='highwaynet_0')
+    assert float(st.vars['h/highwaynet_0/dense2/bias'][0]) == -1.0          # TF initialiser (modules.py:317)
+    cast = (lambda t: t.double()) if dtype == 'float32' else (lambda t: t.float().bfloat16().double())
+    w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
+    _close(y, mo.highwaynet(cast(x), w, 'h/highwaynet_0'), TOL[dtype], 'highway H=%d' % H)
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('H,T', [(40, 400), (128, 60), (256, 24), (24, 33)])
+def test_gru_bidirectional(dtype, H, T):
+    import modules
+    rng = np.random.RandomState(H + T)
+    N = 3
+    st = _store(dtype)
+    x = torch.from_numpy((0.7 * rng.standard_normal((N, T, H))).astype(np.float32))
+    with modules.variable_store(st), modules.variable_scope('g'):
+        y = modules.gru(modules.convert(x.cuda(), st.dtype), num_units=H, bidirection=True)
+    assert y.shape == (N, T, 2 * H)
+    assert float(st.vars['g/gru/bidirectional_rnn/fw/gru_cell/gates/bias'][0]) == 1.0
+    cast = (lambda t: t.double()) if dtype == 'float32' else (lambda t: t.float().bfloat16().double())
+    w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
+    ref = mo.gru_bidirectional(cast(x), w, 'g/gru')
+    _close(y, ref, 5e-5 if dtype == 'float32' else 3e-2, 'gru H=%d' % H)
+
+
+def test_softmax_argmax_exact_ties_and_padding():
+    import modules
+    rng = np.random.RandomState(1)
+    lg = rng.standard_normal((2, 50, 61)).astype(np.float32) * 3
+    lg[0, 0, 5] = lg[0, 0, 17] = 9.0                     # tie -> first index (tf.argmax)
+    lg[1, 3, :] = 0.0                                    # all equal -> class 0
+    d = torch.from_numpy(lg).cuda()
+    p, c = modules.softmax_argmax(d)
+    ref = torch.softmax(torch.from_numpy(lg).double(), -1)
+    _close(p, ref, 1e-6, 'softmax')
+    assert c.dtype == torch.int32
+    assert np.array_equal(c.cpu().numpy(), np.argmax(lg, -1).astype(np.int32))    # exact, incl. ties
+    p64, _ = modules.softmax_argmax(d, pad_to=64, out_dtype=torch.bfloat16)
+    assert p64.shape == (2, 50, 64) and float(p64[:, :, 61:].abs().max()) == 0.0
+    _close(p64[:, :, :61], ref, 4e-3, 'softmax bf16')
+
+
+def test_gemm_argument_errors_are_reported():
+    import _vc
+    import modules
+    st = _store('float32')
+    x = torch.zeros((1, 10, 42), device='cuda')          # Cin not a multiple of 4
+    with modules.variable_store(st), modules.variable_scope('bad'):
+        with pytest.raises((_vc.VCError, ValueError)):
+            modules.conv1d(x, filters=8, size=3, scope='cv')
