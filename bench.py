@@ -10,8 +10,11 @@ section 8e) => weak scaling; the timed region is bracketed by barrier + synchron
 over ranks is reported.
 
 Workloads
-  frontend  BASELINE.json configs[1]: STFT+mel front-end, batch 32 x 4 s @ 16 kHz, fp32
-            (25,632 frames per step and rank).
+  full      (default) the metric's path: STFT+mel front-end on batch 32 x 4 s @ 16 kHz (the input
+            of BASELINE.json configs[1]) -> 64 windows of 400 frames -> encoder + decoder forward
+            (bf16 MFMA, f32 accumulate; --dtype float32 for the exact-f32 path); 25,600 frames
+            per step and rank.
+  frontend  BASELINE.json configs[1] alone: STFT+mel front-end, fp32 (25,632 frames).
 Extra objects on the line: "roofline" (dominant kernel, HIP-event timed on the launch stream),
 "cpu_baseline" (oracle timed on the host, rank 0, N=1 only), "stages".
 """
@@ -114,6 +117,144 @@ def bench_frontend(args, rank, world):
                                'batch': B, 'samples': L, 'frames_per_step_per_gpu': frames}
 
 
+def load_models(dtype, rank):
+    """encoder (real enc_14 weights from the committed trimmed checkpoint) + decoder (random-init
+    weights of the shipped architecture: Glorot kernels, TF default biases -- no decoder checkpoint
+    exists, .gitignore:3 of the reference) at hp/*.json sizes."""
+    import contextlib
+    import io
+    from encoder import encoder_spec_phn
+    from decoder import decoder_specs
+    from aux_func import load_cfg_d
+    hp = os.path.join(ROOT, 'speech-cloner_amd', 'hp')
+    with contextlib.redirect_stdout(io.StringIO()):
+        enc_cfg = load_cfg_d(os.path.join(hp, 'encoder_cfg_d.json'))
+        dec_cfg = load_cfg_d(os.path.join(hp, 'decoder_cfg_d.json'))
+        enc_cfg.update(is_training=False, compute_dtype=dtype,
+                       model_path=os.path.join(ROOT, 'tests', 'golden', 'enc_14_ckpt'))
+        dec_cfg.update(is_training=False)
+        enc = encoder_spec_phn(enc_cfg, None)
+        dec = decoder_specs(dec_cfg, None, enc)
+    return enc, dec
+
+
+ENC_FLOP_PER_FRAME = 482720          # SURVEY.md section 8d
+DEC_FLOP_PER_FRAME = 66321920
+MFMA_BF16_PEAK_TF = 2500.0           # MI355X_MICROARCH.md: dense bf16
+MFMA_F32_PEAK_TF = 157.3
+
+
+def bench_full(args, rank, world):
+    """front-end on 32 x 4 s (configs[1] input) -> first 800 frames of every utterance as two
+    400-frame windows -> encode + decode, `--window-batch` windows per launch."""
+    import audio_lib
+    import modules
+    B, L, T = 32, 64000, 400
+    wav = synth_audio(B, L, seed=rank).cuda()
+    enc, dec = load_models(args.dtype, rank)
+    nwin = B * 2
+    frames = nwin * T
+    fe_out = None
+    res = {}
+
+    def step():
+        nonlocal fe_out
+        fe_out = audio_lib.calc_MFCC_input_batch(wav, None, out=fe_out, **FE_KW)
+        x = fe_out[0][:, :2 * T, :].reshape(nwin, T, 80)
+        for i in range(0, nwin, args.window_batch):
+            o = dec.forward(x[i:i + args.window_batch].contiguous())
+            res[i] = (o['y_mel'], o['y_stft'], o['y_phn'])
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+
+    extra = {}
+    if rank == 0:
+        # dominant-kernel timings with HIP events on the launch stream
+        x = fe_out[0][:, :2 * T, :].reshape(nwin, T, 80)[:args.window_batch].contiguous()
+        st = dec.store
+        W = args.window_batch
+        peak = MFMA_BF16_PEAK_TF if args.dtype == 'bfloat16' else MFMA_F32_PEAK_TF
+        with modules.variable_store(st), modules.variable_scope('decoder'), modules.variable_scope('step2'), \
+                modules.variable_scope('CBHG'):
+            pre = torch.randn(W, T, 256, device='cuda').to(st.dtype)
+            ms_bank = time_events(lambda: modules.conv1d_banks(pre, K=32, is_training=False), 20)
+            bank = modules.conv1d_banks(pre, K=32, is_training=False)
+            ms_p1 = time_events(lambda: modules.conv1d(bank, filters=256, size=3, scope="conv1d_1", bn_scope="conv1d_1",
+                                                       activation_fn='relu', pool_input=True), 20)
+            ms_gru = time_events(lambda: modules.gru(pre, num_units=256, bidirection=True), 5)
+        fl_bank = 2.0 * 256 * 128 * 528 * W * T
+        fl_p1 = 2.0 * 3 * 4096 * 256 * W * T
+        ms_fe = time_events(lambda: audio_lib.calc_MFCC_input_batch(wav, None, out=fe_out, **FE_KW), 20)
+        ms_enc = time_events(lambda: enc.forward(x), 5)
+        ms_all = time_events(lambda: dec.forward(x), 5)
+        ach = fl_bank / (ms_bank * 1e-3) / 1e12
+        extra['roofline'] = {'kernel': 'gemm_kernel<%s> (decoder step2 conv1d_banks, 32 groups)' % args.dtype,
+                             'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
+                             'frac': round(ach / peak, 4), 'traffic': None,
+                             'algorithmic_flop_per_launch': fl_bank, 'avg_kernel_ms': round(ms_bank, 4)}
+        extra['stages'] = {
+            'frontend_ms': round(ms_fe, 4), 'frontend_frames_per_s': round(B * (1 + L // 80) / (ms_fe * 1e-3), 1),
+            'frontend_GBps_vs_8TBps': round(FE_BYTES_PER_FRAME * B * (1 + L // 80) / (ms_fe * 1e-3) / 1e9, 1),
+            'encoder_ms_per_%d_windows' % W: round(ms_enc, 4),
+            'encode_decode_ms_per_%d_windows' % W: round(ms_all, 4),
+            'dec2_bank_ms': round(ms_bank, 4), 'dec2_bank_TFLOPs': round(ach, 2),
+            'dec2_proj1_ms': round(ms_p1, 4), 'dec2_proj1_TFLOPs': round(fl_p1 / (ms_p1 * 1e-3) / 1e12, 2),
+            'dec2_gru_ms': round(ms_gru, 4), 'dec2_gru_us_per_step': round(ms_gru * 1e3 / T, 3),
+            'model_TFLOPs_end_to_end': round((ENC_FLOP_PER_FRAME + DEC_FLOP_PER_FRAME) * W * T / (ms_all * 1e-3) / 1e12, 2)}
+    cfg = {'workload': 'full: STFT+mel front-end on batch 32 x 4 s @ 16 kHz (configs[1] input) -> 64 windows of 400 '
+                       'frames -> encoder (enc_14 weights) + decoder (hp/decoder_cfg_d.json sizes, random init), '
+                       '%d windows per launch' % args.window_batch,
+           'batch': B, 'samples': L, 'windows': nwin, 'frames_per_step_per_gpu': frames, 'model_dtype': args.dtype}
+    return frames, dt, extra, cfg
+
+
+def cpu_baseline_full():
+    """Oracle timed on the host: front-end on 2 utterances (numpy) + encode/decode of 2 windows with
+    torch-CPU float32 ops at the shipped sizes (all host threads)."""
+    from oracle import frontend_oracle as fo
+    from oracle import model_oracle as mo
+    import contextlib
+    import io
+    import tf_bundle
+    from aux_func import load_cfg_d
+    hp = os.path.join(ROOT, 'speech-cloner_amd', 'hp')
+    with contextlib.redirect_stdout(io.StringIO()):
+        enc_cfg = load_cfg_d(os.path.join(hp, 'encoder_cfg_d.json'))
+        dec_cfg = load_cfg_d(os.path.join(hp, 'decoder_cfg_d.json'))
+    w = tf_bundle.read_bundle(os.path.join(ROOT, 'tests', 'golden', 'enc_14_ckpt', 'encoder-136512'), verify_crc=False)
+    we = mo.to_torch({k: v for k, v in w.items() if k.startswith('encoder/')})
+    wd = mo.to_torch(mo.init_weights(dec_cfg, 'decoder', seed=2))
+    wav = synth_audio(2, 64000, seed=0).numpy()
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, 16))                 # the GPU box gives one GPU a 16-core share
+    torch.set_num_threads(ncores)
+    t0 = time.perf_counter()
+    feats = [fo.calc_MFCC_input(wav[b], **FE_KW)[0][:400] for b in range(2)]
+    x = torch.from_numpy(np.stack(feats))
+    with torch.no_grad():
+        _, pr, _, _ = mo.encoder_forward(x, we, enc_cfg)
+        mo.decoder_forward(pr, wd, dec_cfg)
+    dt = time.perf_counter() - t0
+    return {'value': round(800 / dt, 1), 'unit': 'frames/s', 'cores': ncores, 'kind': 'port',
+            'sample': '2 utterances -> 2 windows (800 frames) through oracle/frontend_oracle.py (numpy) and '
+                      'oracle/model_oracle.py (torch-CPU float32, %d threads); one pass, no warm-up' % ncores}
+
+
 def cpu_baseline_frontend():
     """Oracle (numpy/scipy restatement of librosa's path) timed on the host: 8 utterances of the
     same workload (~2-4 s of CPU work per pass, one warm-up + 2 timed passes)."""
@@ -134,9 +275,11 @@ def cpu_baseline_frontend():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='frontend', choices=['frontend'])
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--workload', default='full', choices=['full', 'frontend'])
+    ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
+    ap.add_argument('--window-batch', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
@@ -150,7 +293,10 @@ def main():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
 
-    frames, dt, extra, cfg = bench_frontend(args, rank, world)
+    if args.workload == 'frontend':
+        frames, dt, extra, cfg = bench_frontend(args, rank, world)
+    else:
+        frames, dt, extra, cfg = bench_full(args, rank, world)
 
     t = torch.tensor([dt], dtype=torch.float64, device='cuda')
     if world > 1:
@@ -160,11 +306,12 @@ def main():
         line = {'metric': 'mel frames/sec', 'value': round(frames * world * args.steps / dt, 1), 'unit': 'frames/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(dt / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak',
-                'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+                'vs_baseline': None, 'dtype': 'f32' if args.workload == 'frontend' else
+                ('bf16' if args.dtype == 'bfloat16' else 'f32'), 'data': 'synthetic',
                 'config': dict(cfg, parallelism='utterance-sharded x%d, no collective' % world)}
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline_frontend()
+            line['cpu_baseline'] = cpu_baseline_frontend() if args.workload == 'frontend' else cpu_baseline_full()
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

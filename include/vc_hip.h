@@ -150,7 +150,8 @@ int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, con
  *
  * Optional prologue on A (applied per element, in this order):
  *   pro_scale/pro_shift [Cin] affine, pro_relu, pro_pool: max(A[r], A[r+1]) along time with the
- *   TF "same" rule out[T-1] = x[T-1]  (tf.layers.max_pooling1d(2,1,"same"), modules.py:331).
+ *   TF "same" rule out[T-1] = x[T-1]  (tf.layers.max_pooling1d(2,1,"same"), modules.py:331);
+ *   pro_pool = 2 additionally promises the pooled values are >= 0 (integer-ordered max).
  * Epilogue: v = acc * epi_scale[c] + epi_shift[c] (NULL scale = 1, NULL shift = 0; this is the
  *   dense bias or the folded inference FusedBatchNorm of modules.py:39-102), activation,
  *   + residual R[m, n] (modules.py:340), stored as float32 (out_f32 != 0) or as `dtype`.
@@ -201,9 +202,13 @@ int vc_softmax_argmax(const float* d_logits, int32_t M, int32_t N, int32_t ldl,
  * t = T-1..0.  The input halves of the cell matmuls are hoisted into one GEMM beforehand:
  *   d_xproj float32 [n_seq*T, 6H] = x @ [Wg_x^fw | Wc_x^fw | Wg_x^bw | Wc_x^bw] + biases.
  *   d_Wh[dir]: recurrent weights [H, 3H] = [Wg_h | Wc_h] (rows = h index), dtype w_dtype.
- *   d_out [n_seq*T, 2H] (dtype out_dtype): fw in columns [0,H), bw in [H,2H). */
+ *   d_out [n_seq*T, 2H] (dtype out_dtype): fw in columns [0,H), bw in [H,2H).
+ *   d_workspace: scratch of vc_gru_workspace_bytes(H, w_dtype) bytes (the register-resident
+ *   kernels re-pack the weights into their per-lane order there on every call). */
+size_t vc_gru_workspace_bytes(int32_t H, int32_t w_dtype);
 int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw, int32_t w_dtype,
-                 int32_t n_seq, int32_t T, int32_t H, void* d_out, int32_t out_dtype, void* stream);
+                 int32_t n_seq, int32_t T, int32_t H, void* d_out, int32_t out_dtype,
+                 void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* float32 <-> bf16 conversion of a contiguous buffer (weights preparation, I/O). */
 int vc_convert(const void* d_src, int32_t src_dtype, void* d_dst, int32_t dst_dtype, size_t n, void* stream);

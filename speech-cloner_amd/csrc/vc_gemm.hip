@@ -5,7 +5,8 @@
 // and highwaynet (:297-319, paired-column epilogue).  Contract: include/vc_hip.h (vc_gemm_desc).
 //
 // Tiling: 256 threads = 4 waves (2 x 2), block tile 128 x 128, wave tile 64 x 64 = 2 x 2 MFMA
-// tiles of 32 x 32.  K is consumed in slabs of 128 bytes per row (32 f32 / 64 bf16) staged
+// tiles of 32 x 32 (a 64 x 128 block variant, wave tile 32 x 64, is used when the grid would
+// otherwise leave CUs idle).  K is consumed in slabs of 128 bytes per row (32 f32 / 64 bf16) staged
 // through a double-buffered LDS image with 144-byte rows (16-byte pad => the four 16-lane groups
 // of ds_read_b128 hit 16 distinct slots).  Both operands are K-contiguous (A is a Toeplitz view
 // of the activations, B is the pre-transposed kernel), so global loads are 16 B/lane and a lane's
@@ -24,11 +25,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BM = 128, BN = 128;
+constexpr int BN = 128;                        // block tile: (64*MI) x 128, MI = 1 or 2
 constexpr int ROWB = 144;                      // LDS row pitch in bytes (128 data + 16 pad)
-constexpr int TILE_BYTES = BM * ROWB;          // 18,432
 constexpr int GEMM_THREADS = 256;
-constexpr int GEMM_LDS = 4 * TILE_BYTES;       // A0 B0 A1 B1 = 73,728
+constexpr int lds_bytes(int MI) { return 2 * (64 * MI + BN) * ROWB; }   // A0 B0 A1 B1
 
 template <typename T> struct Tr;
 template <> struct Tr<float> {
@@ -109,57 +109,74 @@ __device__ __forceinline__ bf16x8 vmax(bf16x8 a, bf16x8 b) {
     for (int e = 0; e < 8; ++e) a[e] = ((float)a[e] >= (float)b[e]) ? a[e] : b[e];
     return a;
 }
+// max of NON-NEGATIVE values (post-ReLU): IEEE ordering == unsigned integer ordering of the bit
+// patterns, so bf16 pairs go through v_pk_max_u16 and f32 through v_max_u32.
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 vmax_nonneg(bf16x8 a, bf16x8 b) {
+    const u16x8 r = __builtin_elementwise_max(__builtin_bit_cast(u16x8, a), __builtin_bit_cast(u16x8, b));
+    return __builtin_bit_cast(bf16x8, r);
+}
+__device__ __forceinline__ f32x4 vmax_nonneg(f32x4 a, f32x4 b) {
+    const u32x4 r = __builtin_elementwise_max(__builtin_bit_cast(u32x4, a), __builtin_bit_cast(u32x4, b));
+    return __builtin_bit_cast(f32x4, r);
+}
 
-template <typename T> __device__ __forceinline__ void mma_slab(const char* As, const char* Bs, int wm, int wn,
-                                                               int lane, f32x16 (&acc)[2][2]);
+template <typename T, int MI> struct Mma;
 
-template <> __device__ __forceinline__ void mma_slab<float>(const char* As, const char* Bs, int wm, int wn,
-                                                            int lane, f32x16 (&acc)[2][2]) {
-    const int i = lane & 31, h = lane >> 5;
-    const char* ap = As + (wm * 64 + i) * ROWB + h * 16;
-    const char* bp = Bs + (wn * 64 + i) * ROWB + h * 16;
+template <int MI> struct Mma<float, MI> {
+    static __device__ __forceinline__ void slab(const char* As, const char* Bs, int wm, int wn, int lane,
+                                                f32x16 (&acc)[MI][2]) {
+        const int i = lane & 31, h = lane >> 5;
+        const char* ap = As + (wm * 32 * MI + i) * ROWB + h * 16;
+        const char* bp = Bs + (wn * 64 + i) * ROWB + h * 16;
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        f32x4 av[2], bv[2];
-        av[0] = *reinterpret_cast<const f32x4*>(ap + p * 32);
-        av[1] = *reinterpret_cast<const f32x4*>(ap + 32 * ROWB + p * 32);
-        bv[0] = *reinterpret_cast<const f32x4*>(bp + p * 32);
-        bv[1] = *reinterpret_cast<const f32x4*>(bp + 32 * ROWB + p * 32);
+        for (int p = 0; p < 4; ++p) {
+            f32x4 av[MI], bv[2];
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+            for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const f32x4*>(ap + mi * 32 * ROWB + p * 32);
+            bv[0] = *reinterpret_cast<const f32x4*>(bp + p * 32);
+            bv[1] = *reinterpret_cast<const f32x4*>(bp + 32 * ROWB + p * 32);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][q], bv[ni][q], acc[mi][ni], 0, 0, 0);
+        }
+    }
+};
+
+template <int MI> struct Mma<__bf16, MI> {
+    static __device__ __forceinline__ void slab(const char* As, const char* Bs, int wm, int wn, int lane,
+                                                f32x16 (&acc)[MI][2]) {
+        const int i = lane & 31, h = lane >> 5;
+        const char* ap = As + (wm * 32 * MI + i) * ROWB + h * 16;
+        const char* bp = Bs + (wn * 64 + i) * ROWB + h * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 av[MI], bv[2];
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) av[mi] = *reinterpret_cast<const bf16x8*>(ap + mi * 32 * ROWB + s * 32);
+            bv[0] = *reinterpret_cast<const bf16x8*>(bp + s * 32);
+            bv[1] = *reinterpret_cast<const bf16x8*>(bp + 32 * ROWB + s * 32);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi][q], bv[ni][q], acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+        }
     }
-}
+};
 
-template <> __device__ __forceinline__ void mma_slab<__bf16>(const char* As, const char* Bs, int wm, int wn,
-                                                             int lane, f32x16 (&acc)[2][2]) {
-    const int i = lane & 31, h = lane >> 5;
-    const char* ap = As + (wm * 64 + i) * ROWB + h * 16;
-    const char* bp = Bs + (wn * 64 + i) * ROWB + h * 16;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        bf16x8 av[2], bv[2];
-        av[0] = *reinterpret_cast<const bf16x8*>(ap + s * 32);
-        av[1] = *reinterpret_cast<const bf16x8*>(ap + 32 * ROWB + s * 32);
-        bv[0] = *reinterpret_cast<const bf16x8*>(bp + s * 32);
-        bv[1] = *reinterpret_cast<const bf16x8*>(bp + 32 * ROWB + s * 32);
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-                acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
-    }
-}
-
-template <typename T, int MODE>
+template <typename T, int MODE, int MI>
 __global__ void __launch_bounds__(GEMM_THREADS, 2)
 gemm_kernel(KArgs a) {
     typedef typename Tr<T>::vec_t vec_t;
     constexpr int VEC = Tr<T>::VEC, BK = Tr<T>::BK;
+    constexpr int BM = 64 * MI, AP = 2 * MI;                 // A rows per block, 32-row staging passes
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, BUF_BYTES = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -174,26 +191,27 @@ gemm_kernel(KArgs a) {
     const T* Bt = reinterpret_cast<const T*>(grp.Bt);
 
     const int sc = tid & 7, sr = tid >> 3;
-    int a_t[4];
-    bool a_ok[4], b_ok[4];
+    int a_t[AP];
+    bool a_ok[AP], b_ok[4];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) {
+    for (int p = 0; p < AP; ++p) {
         const int m = m0 + sr + 32 * p;
         a_ok[p] = m < a.M;
         a_t[p] = m % Tn;
-        b_ok[p] = (n0 + sr + 32 * p) < a.N;
     }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) b_ok[p] = (n0 + sr + 32 * p) < a.N;
     const bool has_pro = (a.pro_scale != nullptr) || a.pro_relu;
 
-    vec_t ra[4], rb[4];
+    vec_t ra[AP], rb[4];
     auto gload = [&](int kt) {
         const int kk = kt * BK + sc * VEC;
         const bool kok = kk < K;
         int j = 0, c = kk;
         if (grp.taps > 1) { j = kk / Cin; c = kk - j * Cin; }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            vec_t va = {}, vb = {};
+        for (int p = 0; p < AP; ++p) {
+            vec_t va = {};
             if (kok && a_ok[p]) {
                 const int tt = a_t[p] + j - grp.pad_l;
                 if (tt >= 0 && tt < Tn) {
@@ -203,28 +221,31 @@ gemm_kernel(KArgs a) {
                     if (a.pro_pool && tt + 1 < Tn) {
                         vec_t v2 = *reinterpret_cast<const vec_t*>(ptr + a.ldx);
                         if (has_pro) v2 = pro_apply(v2, a.pro_scale, a.pro_shift, c, a.pro_relu);
-                        va = vmax(va, v2);
+                        va = (a.pro_pool == 2 || a.pro_relu) ? vmax_nonneg(va, v2) : vmax(va, v2);
                     }
                 }
             }
-            if (kok && b_ok[p]) vb = *reinterpret_cast<const vec_t*>(Bt + (size_t)(n0 + sr + 32 * p) * K + kk);
             ra[p] = va;
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            vec_t vb = {};
+            if (kok && b_ok[p]) vb = *reinterpret_cast<const vec_t*>(Bt + (size_t)(n0 + sr + 32 * p) * K + kk);
             rb[p] = vb;
         }
     };
     auto lstore = [&](int buf) {
-        char* As = smem + buf * 2 * TILE_BYTES;
-        char* Bs = As + TILE_BYTES;
+        char* As = smem + buf * BUF_BYTES;
+        char* Bs = As + A_BYTES;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            *reinterpret_cast<vec_t*>(As + (sr + 32 * p) * ROWB + sc * 16) = ra[p];
-            *reinterpret_cast<vec_t*>(Bs + (sr + 32 * p) * ROWB + sc * 16) = rb[p];
-        }
+        for (int p = 0; p < AP; ++p) *reinterpret_cast<vec_t*>(As + (sr + 32 * p) * ROWB + sc * 16) = ra[p];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) *reinterpret_cast<vec_t*>(Bs + (sr + 32 * p) * ROWB + sc * 16) = rb[p];
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -236,8 +257,8 @@ gemm_kernel(KArgs a) {
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
         if (more) gload(kt + 1);
-        const char* As = smem + (kt & 1) * 2 * TILE_BYTES;
-        mma_slab<T>(As, As + TILE_BYTES, wm, wn, lane, acc);
+        const char* As = smem + (kt & 1) * BUF_BYTES;
+        Mma<T, MI>::slab(As, As + A_BYTES, wm, wn, lane, acc);
         if (more) lstore((kt + 1) & 1);
         __syncthreads();
     }
@@ -253,10 +274,10 @@ gemm_kernel(KArgs a) {
             const float s = a.epi_scale ? a.epi_scale[oc] : 1.0f;
             const float b = a.epi_shift ? a.epi_shift[oc] : 0.0f;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int gm = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (gm >= a.M) continue;
                     float v = act_fn(acc[mi][ni][r] * s + b, a.act);
                     if (a.R) v += to_f32(reinterpret_cast<const T*>(a.R)[(size_t)gm * a.ldr + gn]);
@@ -273,10 +294,10 @@ gemm_kernel(KArgs a) {
             const float bH = a.epi_shift ? a.epi_shift[gnH] : 0.0f;
             const float bT = a.epi_shift ? a.epi_shift[gnT] : 0.0f;
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
+            for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int gm = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (gm >= a.M) continue;
                     const float hv = fmaxf(acc[mi][0][r] + bH, 0.0f);
                     const float tv = 1.0f / (1.0f + __expf(-(acc[mi][1][r] + bT)));
@@ -288,28 +309,28 @@ gemm_kernel(KArgs a) {
     }
 }
 
-template <typename T> int launch(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
+template <typename T, int MODE, int MI> int launch_one(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
+    constexpr int BM = 64 * MI;
     const int ntm = (d->M + BM - 1) / BM, ntn = (d->N + BN - 1) / BN;
     dim3 grid(ntm * ntn, d->n_groups), block(GEMM_THREADS);
-    if (d->mode == VC_GEMM_HIGHWAY) {
-        static bool attr_done = false;
-        if (!attr_done) {
-            VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, VC_GEMM_HIGHWAY>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-            attr_done = true;
-        }
-        hipLaunchKernelGGL((gemm_kernel<T, VC_GEMM_HIGHWAY>), grid, block, GEMM_LDS, st, ka);
-    } else {
-        static bool attr_done = false;
-        if (!attr_done) {
-            VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, VC_GEMM_PLAIN>),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS));
-            attr_done = true;
-        }
-        hipLaunchKernelGGL((gemm_kernel<T, VC_GEMM_PLAIN>), grid, block, GEMM_LDS, st, ka);
+    static bool attr_done = false;
+    if (!attr_done) {
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, MODE, MI>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(MI)));
+        attr_done = true;
     }
+    hipLaunchKernelGGL((gemm_kernel<T, MODE, MI>), grid, block, lds_bytes(MI), st, ka);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
+}
+
+template <typename T> int launch(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
+    // 128-row tiles unless that leaves the 256 CUs with fewer than ~2 blocks each
+    const long blocks128 = (long)((d->M + 127) / 128) * ((d->N + BN - 1) / BN) * d->n_groups;
+    const bool small = blocks128 < 512;
+    if (d->mode == VC_GEMM_HIGHWAY)
+        return small ? launch_one<T, VC_GEMM_HIGHWAY, 1>(d, ka, st) : launch_one<T, VC_GEMM_HIGHWAY, 2>(d, ka, st);
+    return small ? launch_one<T, VC_GEMM_PLAIN, 1>(d, ka, st) : launch_one<T, VC_GEMM_PLAIN, 2>(d, ka, st);
 }
 
 }  // namespace

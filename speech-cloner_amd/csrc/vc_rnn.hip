@@ -110,6 +110,185 @@ gru_generic_kernel(GruArgs a) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Register-resident recurrence (H = 128 or 256): NT threads hold the WHOLE recurrent matrix
+// [H, 3H] in VGPRs for all T steps (bf16 at H = 256: 3H^2*2 B = 393 KB of the CU's 512 KB register
+// file = 192 VGPRs per lane at NT = 512, two waves per SIMD; H = 128: NT = 1024, 24 (bf16) or 48
+// (f32) VGPRs per lane).  Per step only h (LDS, bf16
+// copy for v_dot2c_f32_bf16 + f32 copy for the gate arithmetic) and one prefetched row of the
+// hoisted input projections move.
+//   phase 1: thread (col1 = tid / KS1, ks1 = tid % KS1) owns K-slice ks1 of gate column col1 (2H
+//            columns), KS1 = NT / 2H adjacent lanes are summed with DPP-style shuffles;
+//   phase 2: thread (col2 = tid / KS2, ks2) the same for the H candidate columns, KS2 = NT / H.
+// Two barriers per step; h_old of a column lives in the owning thread's register.
+typedef __bf16 bf16x8v __attribute__((ext_vector_type(8)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// Weights arrive PRE-PACKED by gru_pack_kernel in the exact register order:
+//   packed[dir][chunk c][thread tid][EPC elements]  (one 16-byte chunk per lane => coalesced)
+// chunk c of thread tid covers elements j = c*EPC .. c*EPC+EPC-1 of its concatenated slices
+// [phase-1 slice (KL1) | phase-2 slice (KL2)], so the preload is (KL1+KL2)/EPC direct 16-B loads.
+template <typename WT> struct Res;
+template <> struct Res<__bf16> {
+    static constexpr int EPC = 8;                            // elements per 16-byte chunk
+    typedef __bf16 hstore_t;
+    typedef bf16x8v chunk_t;
+    static __device__ __forceinline__ void dot(const chunk_t& w, const __bf16* hs, float& a0, float& a1) {
+        const bf16x8v hv = *reinterpret_cast<const bf16x8v*>(hs);
+        const bf16x2 w0 = {w[0], w[1]}, w1 = {w[2], w[3]}, w2 = {w[4], w[5]}, w3 = {w[6], w[7]};
+        const bf16x2 h0 = {hv[0], hv[1]}, h1 = {hv[2], hv[3]}, h2 = {hv[4], hv[5]}, h3 = {hv[6], hv[7]};
+        a0 = __builtin_amdgcn_fdot2_f32_bf16(w0, h0, a0, false);
+        a1 = __builtin_amdgcn_fdot2_f32_bf16(w1, h1, a1, false);
+        a0 = __builtin_amdgcn_fdot2_f32_bf16(w2, h2, a0, false);
+        a1 = __builtin_amdgcn_fdot2_f32_bf16(w3, h3, a1, false);
+    }
+};
+template <> struct Res<float> {
+    static constexpr int EPC = 4;
+    typedef float hstore_t;
+    typedef f32x4v chunk_t;
+    static __device__ __forceinline__ void dot(const chunk_t& w, const float* hs, float& a0, float& a1) {
+        const f32x4v hv = *reinterpret_cast<const f32x4v*>(hs);
+        a0 = fmaf(w[0], hv[0], a0);
+        a1 = fmaf(w[1], hv[1], a1);
+        a0 = fmaf(w[2], hv[2], a0);
+        a1 = fmaf(w[3], hv[3], a1);
+    }
+};
+
+template <int H, int NT> struct ResGeom {
+    static constexpr int KS1 = NT / (2 * H), KL1 = H / KS1, KS2 = NT / H, KL2 = H / KS2;
+};
+
+// [H, 3H] row-major -> packed register order (see above); one launch handles both directions.
+template <int H, typename WT, int NT>
+__global__ void __launch_bounds__(256)
+gru_pack_kernel(const WT* W0, const WT* W1, WT* packed) {
+    typedef ResGeom<H, NT> G;
+    constexpr int EPC = Res<WT>::EPC, PER = G::KL1 + G::KL2, H3 = 3 * H;
+    const int total = 2 * NT * PER;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        const int dir = idx / (NT * PER);
+        int r = idx - dir * NT * PER;
+        const int c = r / (NT * EPC);
+        r -= c * NT * EPC;
+        const int tid = r / EPC, e = r - tid * EPC;
+        const int j = c * EPC + e;
+        const WT* W = dir ? W1 : W0;
+        WT v;
+        if (j < G::KL1) {
+            const int col1 = tid / G::KS1, ks1 = tid % G::KS1;
+            v = W[(size_t)(ks1 * G::KL1 + j) * H3 + col1];
+        } else {
+            const int col2 = tid / G::KS2, ks2 = tid % G::KS2;
+            v = W[(size_t)(ks2 * G::KL2 + (j - G::KL1)) * H3 + 2 * H + col2];
+        }
+        packed[idx] = v;
+    }
+}
+
+template <int H, typename WT, int NT>
+__global__ void __launch_bounds__(NT, NT / 256)
+gru_resident_kernel(GruArgs a, const WT* packed) {
+    typedef Res<WT> R;
+    typedef ResGeom<H, NT> G;
+    typedef typename R::hstore_t hs_t;
+    typedef typename R::chunk_t chunk_t;
+    constexpr int H3 = 3 * H, EPC = R::EPC;
+    constexpr int KS1 = G::KS1, KL1 = G::KL1, KS2 = G::KS2, KL2 = G::KL2;
+    constexpr int NC1 = KL1 / EPC, NC2 = KL2 / EPC;
+    constexpr int P = EPC;                                   // 16-byte pad between K-slices
+    static_assert(KS1 >= 1 && KS2 <= 64 && KL1 % EPC == 0 && KL2 % EPC == 0, "unsupported H");
+    __shared__ __attribute__((aligned(16))) hs_t hb[KS1 * (KL1 + P)];     // h, sliced for phase 1
+    __shared__ __attribute__((aligned(16))) hs_t rhb[KS2 * (KL2 + P)];    // r*h, sliced for phase 2
+    __shared__ float hf[H];                                               // h in f32 (for r*h)
+    __shared__ float ul[H];                                               // update gate
+
+    const int tid = threadIdx.x;
+    const int seq = blockIdx.x, dir = blockIdx.y;
+    const int col1 = tid / KS1, ks1 = tid % KS1;
+    const int col2 = tid / KS2, ks2 = tid % KS2;
+    chunk_t w1[NC1], w2[NC2];
+    {
+        const chunk_t* pk = reinterpret_cast<const chunk_t*>(packed) + (size_t)dir * NT * (NC1 + NC2) + tid;
+#pragma unroll
+        for (int c = 0; c < NC1; ++c) w1[c] = pk[(size_t)c * NT];
+#pragma unroll
+        for (int c = 0; c < NC2; ++c) w2[c] = pk[(size_t)(NC1 + c) * NT];
+    }
+    for (int i = tid; i < KS1 * (KL1 + P); i += NT) hb[i] = (hs_t)0.0f;
+    for (int i = tid; i < KS2 * (KL2 + P); i += NT) rhb[i] = (hs_t)0.0f;
+    if (tid < H) hf[tid] = 0.0f;
+    const size_t xrow = 6 * (size_t)H;
+    const float* xbase = a.xproj + (size_t)seq * a.T * xrow + (size_t)dir * H3;
+    int t = dir ? a.T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    float xg = (ks1 == 0) ? xbase[(size_t)t * xrow + col1] : 0.0f;
+    float xc = (ks2 == 0) ? xbase[(size_t)t * xrow + 2 * H + col2] : 0.0f;
+    float hreg = 0.0f;
+    const hs_t* hs1 = hb + ks1 * (KL1 + P);
+    const hs_t* hs2 = rhb + ks2 * (KL2 + P);
+    __syncthreads();
+
+    for (int step = 0; step < a.T; ++step, t += dt) {
+        float xg_n = 0.0f, xc_n = 0.0f;
+        if (step + 1 < a.T) {
+            if (ks1 == 0) xg_n = xbase[(size_t)(t + dt) * xrow + col1];
+            if (ks2 == 0) xc_n = xbase[(size_t)(t + dt) * xrow + 2 * H + col2];
+        }
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC1; ++c) R::dot(w1[c], hs1 + c * EPC, a0, a1);
+        float acc = a0 + a1;
+#pragma unroll
+        for (int o = KS1 >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (ks1 == 0) {
+            const float g = sigmoidf_(acc + xg);
+            if (col1 < H) {
+                const int s = col1 / KL2, off = col1 - s * KL2;
+                rhb[s * (KL2 + P) + off] = (hs_t)(g * hf[col1]);
+            } else {
+                ul[col1 - H] = g;
+            }
+        }
+        __syncthreads();
+        float b0 = 0.0f, b1 = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC2; ++c) R::dot(w2[c], hs2 + c * EPC, b0, b1);
+        float acc2 = b0 + b1;
+#pragma unroll
+        for (int o = KS2 >> 1; o > 0; o >>= 1) acc2 += __shfl_xor(acc2, o, 64);
+        if (ks2 == 0) {
+            const float c = tanhf(acc2 + xc);
+            const float uu = ul[col2];
+            const float hn = uu * hreg + (1.0f - uu) * c;
+            hreg = hn;
+            const int s = col2 / KL1, off = col2 - s * KL1;
+            hb[s * (KL1 + P) + off] = (hs_t)hn;
+            hf[col2] = hn;
+            st_out<WT>(a.out, ((size_t)seq * a.T + t) * 2 * H + (size_t)dir * H + col2, hn, a.out_bf16);
+        }
+        __syncthreads();
+        xg = xg_n;
+        xc = xc_n;
+    }
+}
+
+template <int H, typename WT, int NT>
+int launch_resident(const GruArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    const size_t need = 2 * (size_t)3 * H * H * sizeof(WT);
+    if (ws == nullptr || ws_bytes < need)
+        return vc::set_error(VC_ERR_WORKSPACE, "vc_gru_bidir: workspace too small (%zu < %zu)", ws_bytes, need);
+    WT* packed = static_cast<WT*>(ws);
+    hipLaunchKernelGGL((gru_pack_kernel<H, WT, NT>), dim3(256), dim3(256), 0, st,
+                       static_cast<const WT*>(a.Wh[0]), static_cast<const WT*>(a.Wh[1]), packed);
+    hipLaunchKernelGGL((gru_resident_kernel<H, WT, NT>), dim3(a.n_seq, 2), dim3(NT), 0, st, a,
+                       static_cast<const WT*>(packed));
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 softmax_argmax_kernel(const float* logits, int M, int N, int ldl, void* prob, int ldp, int out_bf16, int32_t* cls) {
@@ -157,8 +336,14 @@ convert_kernel(const void* src, int sdt, void* dst, int ddt, size_t n) {
 
 extern "C" {
 
+size_t vc_gru_workspace_bytes(int32_t H, int32_t w_dtype) {
+    if (H <= 0) return 0;
+    return 2 * (size_t)3 * H * H * (w_dtype == VC_F32 ? 4 : 2);
+}
+
 int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw, int32_t w_dtype, int32_t n_seq,
-                 int32_t T, int32_t H, void* d_out, int32_t out_dtype, void* stream) {
+                 int32_t T, int32_t H, void* d_out, int32_t out_dtype, void* d_workspace, size_t workspace_bytes,
+                 void* stream) {
     VC_REQUIRE(d_xproj && d_Wh_fw && d_Wh_bw && d_out, "NULL argument");
     VC_REQUIRE(n_seq > 0 && T > 0 && H > 0 && H <= 1024, "bad shape n_seq=%d T=%d H=%d", n_seq, T, H);
     VC_REQUIRE(w_dtype == VC_F32 || w_dtype == VC_BF16, "bad w_dtype %d", w_dtype);
@@ -174,6 +359,10 @@ int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw,
     while (nt < 512 && nt < 2 * H) nt *= 2;
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(n_seq, 2);
+    // register-resident kernels for the decoder's sizes
+    if (w_dtype == VC_BF16 && H == 256) return launch_resident<256, __bf16, 512>(a, d_workspace, workspace_bytes, st);
+    if (w_dtype == VC_BF16 && H == 128) return launch_resident<128, __bf16, 1024>(a, d_workspace, workspace_bytes, st);
+    if (w_dtype == VC_F32 && H == 128) return launch_resident<128, float, 1024>(a, d_workspace, workspace_bytes, st);
     if (w_dtype == VC_F32) {
         VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_generic_kernel<float>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

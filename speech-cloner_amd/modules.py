@@ -340,7 +340,9 @@ def conv1d(inputs, filters=None, size=1, rate=1, padding="SAME", use_bias=False,
       bn_scope    inference batch norm of that scope folded into the epilogue (modules.py:335,338)
       activation_fn 'relu' after the norm
       residual    tensor added after the norm (modules.py:340)
-      pool_input  max_pooling1d(2, 1, 'same') applied to ``inputs`` on the fly (modules.py:331)"""
+      pool_input  max_pooling1d(2, 1, 'same') applied to ``inputs`` on the fly (modules.py:331);
+                  2 = same, with the promise that ``inputs`` >= 0 (post-ReLU) so the max runs on
+                  the integer bit patterns"""
     if rate != 1 or padding.upper() != "SAME" or use_bias:
         raise NotImplementedError(' - ERROR, conv1d: only rate=1, padding=SAME, use_bias=False are used by the reference')
     torch = _torch()
@@ -357,7 +359,7 @@ def conv1d(inputs, filters=None, size=1, rate=1, padding="SAME", use_bias=False,
     out = torch.empty((N_, T_, filters), dtype=store.dtype, device=x.device)
     act = {None: _vc.ACT_NONE, 'relu': _vc.ACT_RELU}[activation_fn]
     gemm_launch(x, N_ * T_, T_, Cin, Cin, filters, [(bt, size * Cin, size, (size - 1) // 2, 0)], out, filters,
-                store.vc_dtype, pro_pool=pool_input, epi_scale=s, epi_shift=sh, act=act,
+                store.vc_dtype, pro_pool=int(pool_input), epi_scale=s, epi_shift=sh, act=act,
                 R=residual, ldr=filters if residual is not None else 0)
     return out
 
@@ -403,8 +405,11 @@ def gru(inputs, num_units=None, bidirection=False, scope="gru", use_Cudnn=False,
     gemm_launch(x, N_ * T_, T_, Cin, Cin, 6 * H, [(btx, Cin, 1, 0, 0)], xproj, 6 * H, store.vc_dtype,
                 epi_shift=bx, out_f32=True)
     out = torch.empty((N_, T_, 2 * H), dtype=store.dtype, device=x.device)
+    nws = _vc.lib().vc_gru_workspace_bytes(H, store.vc_dtype)
+    ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=x.device)
     _vc.check(_vc.lib().vc_gru_bidir(xproj.data_ptr(), wh_fw.data_ptr(), wh_bw.data_ptr(), store.vc_dtype,
-                                     N_, T_, H, out.data_ptr(), store.vc_dtype, _vc.current_stream()))
+                                     N_, T_, H, out.data_ptr(), store.vc_dtype, ws.data_ptr(), nws,
+                                     _vc.current_stream()))
     return out
 
 
@@ -458,7 +463,7 @@ def CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dro
         enc = conv1d_banks(inputs, K=num_conv_banks, is_training=is_training)              # (N, T, K*128)
         # max pooling (modules.py:331) is fused into conv1d_1's operand load
         enc = conv1d(enc, filters=embed_size // 2, size=3, scope="conv1d_1", bn_scope="conv1d_1",
-                     activation_fn='relu', pool_input=True)                                # (N, T, E/2)
+                     activation_fn='relu', pool_input=2)   # 2: operand is post-ReLU (>= 0)   (N, T, E/2)
         enc = conv1d(enc, filters=embed_size // 2, size=3, scope="conv1d_2", bn_scope="conv1d_2",
                      residual=inputs)                                                      # + residual
         for i in range(num_highwaynet_blocks):
