@@ -279,7 +279,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--workload', default='full', choices=['full', 'frontend'])
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
-    ap.add_argument('--window-batch', type=int, default=32)
+    ap.add_argument('--window-batch', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 

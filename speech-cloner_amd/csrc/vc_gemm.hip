@@ -13,8 +13,8 @@
 // MFMA fragment is one ds_read_b128:
 //   f32 : v_mfma_f32_32x32x2_f32, exact f32 fma chain; the 4 floats of a 16-B chunk feed 4 MFMAs
 //   bf16: v_mfma_f32_32x32x16_bf16, f32 accumulate; a 16-B chunk is one MFMA's 8-element fragment
-// Register-staged pipeline: global loads of slab t+1 are issued before the MFMAs of slab t and
-// written to the other LDS buffer after them (one barrier per slab).
+// Register-staged pipeline: the (branch-free, unconditional) global loads of slab t+1 are issued
+// before the MFMAs of slab t and written to the other LDS buffer after them; one barrier per slab.
 #include <hip/hip_runtime.h>
 
 #include "vc_common.h"
@@ -170,7 +170,9 @@ template <int MI> struct Mma<__bf16, MI> {
     }
 };
 
-template <typename T, int MODE, int MI>
+// PRO: 0 = plain operand, 1 = time max-pool of the operand, 2 = per-channel affine (+relu)
+// (+ pool) -- the training path's "normalise the previous layer on the fly".
+template <typename T, int MODE, int MI, int PRO>
 __global__ void __launch_bounds__(GEMM_THREADS, 2)
 gemm_kernel(KArgs a) {
     typedef typename Tr<T>::vec_t vec_t;
@@ -190,57 +192,87 @@ gemm_kernel(KArgs a) {
     const T* X = reinterpret_cast<const T*>(a.X);
     const T* Bt = reinterpret_cast<const T*>(grp.Bt);
 
+    // ---- operand staging: lane (sr, sc) owns the 16-byte chunk sc of rows sr + 32 p.
+    // Loads are UNCONDITIONAL (addresses clamped into the tensors, zero selected afterwards): a
+    // branch around a load makes hipcc wait vmcnt(0) per load and serialises the whole slab.
     const int sc = tid & 7, sr = tid >> 3;
+    const T* a_row[AP];                                  // X row of this lane's tile row (clamped)
     int a_t[AP];
     bool a_ok[AP], b_ok[4];
+    const T* b_row[4];
 #pragma unroll
     for (int p = 0; p < AP; ++p) {
         const int m = m0 + sr + 32 * p;
         a_ok[p] = m < a.M;
-        a_t[p] = m % Tn;
+        const int mm = min(m, a.M - 1);
+        a_t[p] = mm % Tn;
+        a_row[p] = X + (size_t)mm * a.ldx;
     }
 #pragma unroll
-    for (int p = 0; p < 4; ++p) b_ok[p] = (n0 + sr + 32 * p) < a.N;
-    const bool has_pro = (a.pro_scale != nullptr) || a.pro_relu;
+    for (int p = 0; p < 4; ++p) {
+        const int n = n0 + sr + 32 * p;
+        b_ok[p] = n < a.N;
+        b_row[p] = Bt + (size_t)min(n, a.N - 1) * K;
+    }
+    const int pad_l = grp.pad_l, ldx = a.ldx;
+    const bool pool = PRO >= 1 && a.pro_pool != 0;
+    const bool nonneg = a.pro_pool == 2 || a.pro_relu;
 
-    vec_t ra[AP], rb[4];
-    auto gload = [&](int kt) {
-        const int kk = kt * BK + sc * VEC;
-        const bool kok = kk < K;
-        int j = 0, c = kk;
-        if (grp.taps > 1) { j = kk / Cin; c = kk - j * Cin; }
+    // gload() only ISSUES the 16-byte loads (and remembers which chunks are real); everything that
+    // consumes them -- prologue, pool max, zero select, ds_write -- happens in lstore() after the
+    // slab's MFMAs, so all loads of a slab are in flight together behind the matrix work.
+    vec_t ra[AP], ra2[PRO >= 1 ? AP : 1], rb[4];
+    unsigned okbits = 0;                                 // bit p: A chunk p valid, bit 8+p: B chunk p valid
+    int st_c = 0;                                        // channel of the staged A chunk (prologue tables)
+    int g_kk = sc * VEC, g_j = 0, g_c = sc * VEC;        // this lane's chunk in the next slab to load
+    if (grp.taps > 1) { g_j = g_c / Cin; g_c -= g_j * Cin; }
+    auto gload = [&]() {
+        const bool kok = g_kk < K;
+        const int j = kok ? g_j : 0, c = kok ? g_c : 0, kb = kok ? g_kk : 0;
+        const int dj = j - pad_l;
+        unsigned bits = 0;
 #pragma unroll
         for (int p = 0; p < AP; ++p) {
-            vec_t va = {};
-            if (kok && a_ok[p]) {
-                const int tt = a_t[p] + j - grp.pad_l;
-                if (tt >= 0 && tt < Tn) {
-                    const T* ptr = X + (size_t)(m0 + sr + 32 * p + j - grp.pad_l) * a.ldx + c;
-                    va = *reinterpret_cast<const vec_t*>(ptr);
-                    if (has_pro) va = pro_apply(va, a.pro_scale, a.pro_shift, c, a.pro_relu);
-                    if (a.pro_pool && tt + 1 < Tn) {
-                        vec_t v2 = *reinterpret_cast<const vec_t*>(ptr + a.ldx);
-                        if (has_pro) v2 = pro_apply(v2, a.pro_scale, a.pro_shift, c, a.pro_relu);
-                        va = (a.pro_pool == 2 || a.pro_relu) ? vmax_nonneg(va, v2) : vmax(va, v2);
-                    }
-                }
+            const int tt = a_t[p] + dj;
+            const bool ok = kok && a_ok[p] && tt >= 0 && tt < Tn;
+            const T* ptr = a_row[p] + (ok ? dj * ldx : 0) + c;
+            ra[p] = *reinterpret_cast<const vec_t*>(ptr);
+            if (PRO >= 1) {
+                const T* ptr2 = ptr + ((pool && ok && tt + 1 < Tn) ? ldx : 0);   // last frame pools with itself
+                ra2[p] = *reinterpret_cast<const vec_t*>(ptr2);
             }
-            ra[p] = va;
+            bits |= (ok ? 1u : 0u) << p;
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            vec_t vb = {};
-            if (kok && b_ok[p]) vb = *reinterpret_cast<const vec_t*>(Bt + (size_t)(n0 + sr + 32 * p) * K + kk);
-            rb[p] = vb;
+            rb[p] = *reinterpret_cast<const vec_t*>(b_row[p] + kb);
+            bits |= ((kok && b_ok[p]) ? 1u : 0u) << (8 + p);
         }
+        okbits = bits;
+        st_c = c;
+        g_kk += BK;
+        g_c += BK;
+        if (grp.taps > 1)
+            while (g_c >= Cin) { g_c -= Cin; ++g_j; }
     };
     auto lstore = [&](int buf) {
         char* As = smem + buf * BUF_BYTES;
         char* Bs = As + A_BYTES;
+        const vec_t zero = {};
 #pragma unroll
-        for (int p = 0; p < AP; ++p) *reinterpret_cast<vec_t*>(As + (sr + 32 * p) * ROWB + sc * 16) = ra[p];
+        for (int p = 0; p < AP; ++p) {
+            vec_t v = ra[p];
+            if (PRO == 2) v = pro_apply(v, a.pro_scale, a.pro_shift, st_c, a.pro_relu);
+            if (PRO >= 1) {
+                vec_t v2 = ra2[p];
+                if (PRO == 2) v2 = pro_apply(v2, a.pro_scale, a.pro_shift, st_c, a.pro_relu);
+                if (pool) v = nonneg ? vmax_nonneg(v, v2) : vmax(v, v2);
+            }
+            *reinterpret_cast<vec_t*>(As + (sr + 32 * p) * ROWB + sc * 16) = ((okbits >> p) & 1u) ? v : zero;
+        }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<vec_t*>(Bs + (sr + 32 * p) * ROWB + sc * 16) = rb[p];
+        for (int p = 0; p < 4; ++p)
+            *reinterpret_cast<vec_t*>(Bs + (sr + 32 * p) * ROWB + sc * 16) = ((okbits >> (8 + p)) & 1u) ? rb[p] : zero;
     };
 
     f32x16 acc[MI][2];
@@ -251,12 +283,12 @@ gemm_kernel(KArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    gload(0);
+    gload();
     lstore(0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = kt + 1 < nk;
-        if (more) gload(kt + 1);
+        if (more) gload();                               // slab kt+1 in flight during the MFMAs
         const char* As = smem + (kt & 1) * BUF_BYTES;
         Mma<T, MI>::slab(As, As + A_BYTES, wm, wn, lane, acc);
         if (more) lstore((kt + 1) & 1);
@@ -309,28 +341,251 @@ gemm_kernel(KArgs a) {
     }
 }
 
-template <typename T, int MODE, int MI> int launch_one(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
+
+// ------------------------------------------------------------------------------------------
+// Convolution-specialised variant (taps > 1, Cin a multiple of the slab width): the K loop runs
+// channel-slab OUTER, tap INNER, and ONE activation tile of BM + taps - 1 rows stays in LDS for
+// all taps of a channel slab (tap j's A fragment is the same image read j rows further down), so
+// per slab only the B tile streams.  That cuts the global->LDS operand traffic of the banks by
+// ~2x and of the k = 3 projections by ~3x (their pooled operand is built once, not per tap) --
+// the 128 x 128 bf16 tile is otherwise L2->LDS bandwidth bound.
+// The zeros of TF's SAME padding depend on (output row, tap), not on the LDS row, so they are
+// applied as a select on the fragment after the ds_read (lane i owns output rows with fixed t).
+constexpr int CONV_MAX_TAPS = 32;
+constexpr int conv_lds_bytes() { return (128 + CONV_MAX_TAPS - 1) * ROWB + 2 * BN * ROWB; }   // A | B0 B1
+
+template <typename T, int PRO>
+__global__ void __launch_bounds__(GEMM_THREADS, 2)
+conv_kernel(KArgs a) {
+    typedef typename Tr<T>::vec_t vec_t;
+    constexpr int VEC = Tr<T>::VEC, BK = Tr<T>::BK;      // BK = channels per slab
+    constexpr int BM = 128, MI = 2;
+    constexpr int A_BYTES = (BM + CONV_MAX_TAPS - 1) * ROWB, B_BYTES = BN * ROWB;
+    constexpr int NAP = 5;                                // ceil((128 + 31) * 8 / 256) staging passes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const As = smem;
+    char* const Bs0 = smem + A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const KGroup grp = a.g[a.n_groups - 1 - (int)blockIdx.y];
+    const int ntn = (a.N + BN - 1) / BN;
+    const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int K = grp.K, Cin = a.Cin, Tn = a.T, taps = grp.taps, pad_l = grp.pad_l, ldx = a.ldx;
+    const int ncs = Cin / BK;
+    const int NR = BM + taps - 1;                         // rows of the resident A tile
+    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* Bt = reinterpret_cast<const T*>(grp.Bt);
+    const bool pool = PRO >= 1 && a.pro_pool != 0;
+    const bool nonneg = a.pro_pool == 2 || a.pro_relu;
+
+    // ---- staging roles: chunk sc of tile rows sr + 32 p
+    const int sc = tid & 7, sr = tid >> 3;
+    const T* a_row[NAP];
+    const T* a_row2[NAP];
+    bool a_in[NAP];
+#pragma unroll
+    for (int p = 0; p < NAP; ++p) {
+        const int r = sr + 32 * p;                        // tile row
+        a_in[p] = r < NR;
+        const int g = min(max(m0 - pad_l + r, 0), a.M - 1);   // global row (clamped; masked at read)
+        a_row[p] = X + (size_t)g * ldx + sc * VEC;
+        const bool nxt = pool && (g % Tn) + 1 < Tn;       // TF same-pool: last frame pools with itself
+        a_row2[p] = a_row[p] + (nxt ? ldx : 0);
+    }
+    const T* b_row[4];
+    bool b_ok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int n = n0 + sr + 32 * p;
+        b_ok[p] = n < a.N;
+        b_row[p] = Bt + (size_t)min(n, a.N - 1) * K + sc * VEC;
+    }
+    // ---- MFMA roles: lane i of wave (wm, wn) owns output rows wm*64 + mi*32 + i
+    const int li = lane & 31, lh = lane >> 5;
+    int jlo[MI], jhi[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const int m = min(m0 + wm * 64 + mi * 32 + li, a.M - 1);
+        const int t = m % Tn;
+        jlo[mi] = max(0, pad_l - t);                      // taps [jlo, jhi) see a real frame
+        jhi[mi] = min(taps, Tn - t + pad_l);
+    }
+
+    vec_t ra[NAP], ra2[PRO >= 1 ? NAP : 1], rb[4];
+    auto gloadA = [&](int cs) {
+        const int c = cs * BK;
+#pragma unroll
+        for (int p = 0; p < NAP; ++p) {
+            ra[p] = *reinterpret_cast<const vec_t*>(a_row[p] + c);
+            if (PRO >= 1) ra2[p] = *reinterpret_cast<const vec_t*>(a_row2[p] + c);
+        }
+    };
+    auto lstoreA = [&](int cs) {
+        const int c = cs * BK + sc * VEC;
+#pragma unroll
+        for (int p = 0; p < NAP; ++p) {
+            vec_t v = ra[p];
+            if (PRO == 2) v = pro_apply(v, a.pro_scale, a.pro_shift, c, a.pro_relu);
+            if (PRO >= 1) {
+                vec_t v2 = ra2[p];
+                if (PRO == 2) v2 = pro_apply(v2, a.pro_scale, a.pro_shift, c, a.pro_relu);
+                if (pool) v = nonneg ? vmax_nonneg(v, v2) : vmax(v, v2);
+            }
+            if (a_in[p]) *reinterpret_cast<vec_t*>(As + (sr + 32 * p) * ROWB + sc * 16) = v;
+        }
+    };
+    auto gloadB = [&](int cs, int j) {
+        const int kb = j * Cin + cs * BK;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) rb[p] = *reinterpret_cast<const vec_t*>(b_row[p] + kb);
+    };
+    auto lstoreB = [&](int buf) {
+        char* Bs = Bs0 + buf * B_BYTES;
+        const vec_t zero = {};
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            *reinterpret_cast<vec_t*>(Bs + (sr + 32 * p) * ROWB + sc * 16) = b_ok[p] ? rb[p] : zero;
+    };
+
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+
+    gloadA(0);
+    gloadB(0, 0);
+    lstoreA(0);
+    lstoreB(0);
+    __syncthreads();
+    const int nit = ncs * taps;
+    int cs = 0, j = 0;
+    for (int it = 0; it < nit; ++it) {
+        int cs_n = cs, j_n = j + 1;
+        if (j_n == taps) { j_n = 0; cs_n = cs + 1; }
+        const bool more = it + 1 < nit;
+        if (more) gloadB(cs_n, j_n);
+        const bool stageA = (j == 0) && (cs + 1 < ncs);   // next channel slab's tile: long flight
+        if (stageA) gloadA(cs + 1);
+        {   // MFMAs of slab (cs, j): A fragment = resident tile shifted down by j rows
+            const char* Bs = Bs0 + (it & 1) * B_BYTES;
+            const char* ap = As + (wm * 64 + li + j) * ROWB + lh * 16;
+            const char* bp = Bs + (wn * 64 + li) * ROWB + lh * 16;
+            const bool v0 = j >= jlo[0] && j < jhi[0], v1 = j >= jlo[1] && j < jhi[1];
+            const vec_t zero = {};
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                vec_t av0 = *reinterpret_cast<const vec_t*>(ap + s4 * 32);
+                vec_t av1 = *reinterpret_cast<const vec_t*>(ap + 32 * ROWB + s4 * 32);
+                const vec_t bv0 = *reinterpret_cast<const vec_t*>(bp + s4 * 32);
+                const vec_t bv1 = *reinterpret_cast<const vec_t*>(bp + 32 * ROWB + s4 * 32);
+                av0 = v0 ? av0 : zero;
+                av1 = v1 ? av1 : zero;
+                if constexpr (sizeof(T) == 2) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av0, bv0, acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av0, bv1, acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av1, bv0, acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av1, bv1, acc[1][1], 0, 0, 0);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[q], bv0[q], acc[0][0], 0, 0, 0);
+                        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[q], bv1[q], acc[0][1], 0, 0, 0);
+                        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[q], bv0[q], acc[1][0], 0, 0, 0);
+                        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[q], bv1[q], acc[1][1], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (j == taps - 1 && cs + 1 < ncs) {              // retire the resident tile, bring in the next
+            __syncthreads();
+            lstoreA(cs + 1);
+        }
+        if (more) lstoreB((it + 1) & 1);
+        __syncthreads();
+        cs = cs_n;
+        j = j_n;
+    }
+
+    // ---------------------------------------------------------------------------- epilogue
+    const int i = li, h = lh;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int gn = n0 + wn * 64 + ni * 32 + i;
+        if (gn >= a.N) continue;
+        const int oc = grp.c_off + gn;
+        const float sv = a.epi_scale ? a.epi_scale[oc] : 1.0f;
+        const float bv = a.epi_shift ? a.epi_shift[oc] : 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (gm >= a.M) continue;
+                float v = act_fn(acc[mi][ni][r] * sv + bv, a.act);
+                if (a.R) v += to_f32(reinterpret_cast<const T*>(a.R)[(size_t)gm * a.ldr + gn]);
+                store_out<T>(a.C, (size_t)gm * a.ldc + oc, v, a.out_f32);
+            }
+        }
+    }
+}
+
+template <typename T, int PRO> int launch_conv(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
+    const int ntm = (d->M + 127) / 128, ntn = (d->N + BN - 1) / BN;
+    static bool attr_done = false;
+    if (!attr_done) {
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_kernel<T, PRO>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes()));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_kernel<T, PRO>), dim3(ntm * ntn, d->n_groups), dim3(GEMM_THREADS), conv_lds_bytes(), st, ka);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+template <typename T, int MODE, int MI, int PRO> int launch_one(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
     constexpr int BM = 64 * MI;
     const int ntm = (d->M + BM - 1) / BM, ntn = (d->N + BN - 1) / BN;
     dim3 grid(ntm * ntn, d->n_groups), block(GEMM_THREADS);
     static bool attr_done = false;
     if (!attr_done) {
-        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, MODE, MI>),
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<T, MODE, MI, PRO>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(MI)));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<T, MODE, MI>), grid, block, lds_bytes(MI), st, ka);
+    hipLaunchKernelGGL((gemm_kernel<T, MODE, MI, PRO>), grid, block, lds_bytes(MI), st, ka);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }
 
+template <typename T, int MI> int launch_mi(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
+    if (d->mode == VC_GEMM_HIGHWAY) return launch_one<T, VC_GEMM_HIGHWAY, MI, 0>(d, ka, st);
+    if (d->d_pro_scale || d->pro_relu) return launch_one<T, VC_GEMM_PLAIN, MI, 2>(d, ka, st);
+    if (d->pro_pool) return launch_one<T, VC_GEMM_PLAIN, MI, 1>(d, ka, st);
+    return launch_one<T, VC_GEMM_PLAIN, MI, 0>(d, ka, st);
+}
+
 template <typename T> int launch(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
+    // convolution-specialised kernel: every group has taps in [2, 32] (a grouped bank launch may
+    // include its k = 1 member) and Cin is a whole number of channel slabs
+    bool conv_ok = d->mode == VC_GEMM_PLAIN && d->Cin % Tr<T>::BK == 0 && d->M >= 128;
+    int max_taps = 1;
+    for (int g = 0; g < d->n_groups; ++g) {
+        if (d->groups[g].taps > CONV_MAX_TAPS) conv_ok = false;
+        if (d->groups[g].taps > max_taps) max_taps = d->groups[g].taps;
+    }
+    if (conv_ok && max_taps > 1) {
+        if (d->d_pro_scale || d->pro_relu) return launch_conv<T, 2>(d, ka, st);
+        if (d->pro_pool) return launch_conv<T, 1>(d, ka, st);
+        return launch_conv<T, 0>(d, ka, st);
+    }
     // 128-row tiles unless that leaves the 256 CUs with fewer than ~2 blocks each
     const long blocks128 = (long)((d->M + 127) / 128) * ((d->N + BN - 1) / BN) * d->n_groups;
-    const bool small = blocks128 < 512;
-    if (d->mode == VC_GEMM_HIGHWAY)
-        return small ? launch_one<T, VC_GEMM_HIGHWAY, 1>(d, ka, st) : launch_one<T, VC_GEMM_HIGHWAY, 2>(d, ka, st);
-    return small ? launch_one<T, VC_GEMM_PLAIN, 1>(d, ka, st) : launch_one<T, VC_GEMM_PLAIN, 2>(d, ka, st);
+    return blocks128 < 512 ? launch_mi<T, 1>(d, ka, st) : launch_mi<T, 2>(d, ka, st);
 }
 
 }  // namespace
@@ -349,8 +604,9 @@ extern "C" int vc_conv_gemm(const vc_gemm_desc* d, void* stream) {
     VC_REQUIRE((reinterpret_cast<uintptr_t>(d->d_X) & 15) == 0, "X must be 16-byte aligned");
     VC_REQUIRE(!(d->d_pro_scale == nullptr) == !(d->d_pro_shift == nullptr), "pro_scale and pro_shift go together");
     if (d->mode == VC_GEMM_HIGHWAY)
-        VC_REQUIRE(d->n_groups == 1 && d->groups[0].taps == 1 && d->N % 64 == 0 && d->N >= 2 * d->Cin && !d->d_R,
-                   "highway mode: one group, taps 1, N = 64*ceil(H/32) paired columns, no residual");
+        VC_REQUIRE(d->n_groups == 1 && d->groups[0].taps == 1 && d->N % 64 == 0 && d->N >= 2 * d->Cin && !d->d_R &&
+                       !d->d_pro_scale && !d->pro_relu && !d->pro_pool,
+                   "highway mode: one group, taps 1, N = 64*ceil(H/32) paired columns, no residual, no prologue");
     KArgs ka;
     ka.X = d->d_X; ka.M = d->M; ka.T = d->T; ka.Cin = d->Cin; ka.ldx = d->ldx; ka.N = d->N; ka.n_groups = d->n_groups;
     ka.pro_scale = d->d_pro_scale; ka.pro_shift = d->d_pro_shift; ka.pro_relu = d->pro_relu; ka.pro_pool = d->pro_pool;

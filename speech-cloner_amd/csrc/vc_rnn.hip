@@ -289,6 +289,63 @@ int launch_resident(const GruArgs& a, void* ws, size_t ws_bytes, hipStream_t st)
     return VC_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Single-wave recurrence for small H (the encoder: H = 40): one 64-lane wave per (window,
+// direction), no LDS and no barriers.  Lane j owns hidden unit j: its three weight columns
+// (r_j, u_j, c_j: 3H f32 registers) and h_j.  h is broadcast to the wave one element at a time
+// with v_readlane (the value becomes a scalar operand of the FMAs).
+template <int H, typename WT>
+__global__ void __launch_bounds__(64)
+gru_wave_kernel(GruArgs a) {
+    static_assert(H <= 64, "one lane per hidden unit");
+    constexpr int H3 = 3 * H;
+    const int lane = threadIdx.x;
+    const int seq = blockIdx.x, dir = blockIdx.y;
+    const bool act = lane < H;
+    const int j = act ? lane : 0;
+    const WT* W = reinterpret_cast<const WT*>(a.Wh[dir]);
+    float wr[H], wu[H], wc[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) {
+        wr[k] = act ? ld_w(W + (size_t)k * H3 + j) : 0.0f;
+        wu[k] = act ? ld_w(W + (size_t)k * H3 + H + j) : 0.0f;
+        wc[k] = act ? ld_w(W + (size_t)k * H3 + 2 * H + j) : 0.0f;
+    }
+    const size_t xrow = 6 * (size_t)H;
+    const float* xbase = a.xproj + (size_t)seq * a.T * xrow + (size_t)dir * H3 + j;
+    int t = dir ? a.T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    float xr = xbase[(size_t)t * xrow], xu = xbase[(size_t)t * xrow + H], xc = xbase[(size_t)t * xrow + 2 * H];
+    float h = 0.0f;
+    for (int step = 0; step < a.T; ++step, t += dt) {
+        float xr_n = 0.0f, xu_n = 0.0f, xc_n = 0.0f;
+        if (step + 1 < a.T) {
+            const float* xn = xbase + (size_t)(t + dt) * xrow;
+            xr_n = xn[0]; xu_n = xn[H]; xc_n = xn[2 * H];
+        }
+        float ar = xr, au = xu;
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const float hk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k));
+            ar = fmaf(hk, wr[k], ar);
+            au = fmaf(hk, wu[k], au);
+        }
+        const float r = sigmoidf_(ar), u = sigmoidf_(au);
+        const float rh = r * h;
+        float ac = xc;
+#pragma unroll
+        for (int k = 0; k < H; ++k) {
+            const float rk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rh), k));
+            ac = fmaf(rk, wc[k], ac);
+        }
+        const float c = tanhf(ac);
+        h = act ? (u * h + (1.0f - u) * c) : 0.0f;
+        if (act) st_out<WT>(a.out, ((size_t)seq * a.T + t) * 2 * H + (size_t)dir * H + j, h, a.out_bf16);
+        xr = xr_n; xu = xu_n; xc = xc_n;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 softmax_argmax_kernel(const float* logits, int M, int N, int ldl, void* prob, int ldp, int out_bf16, int32_t* cls) {
@@ -363,6 +420,12 @@ int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw,
     if (w_dtype == VC_BF16 && H == 256) return launch_resident<256, __bf16, 512>(a, d_workspace, workspace_bytes, st);
     if (w_dtype == VC_BF16 && H == 128) return launch_resident<128, __bf16, 1024>(a, d_workspace, workspace_bytes, st);
     if (w_dtype == VC_F32 && H == 128) return launch_resident<128, float, 1024>(a, d_workspace, workspace_bytes, st);
+    if (H == 40) {                                      // the shipped encoder (hp/encoder_cfg_d.json)
+        if (w_dtype == VC_F32) hipLaunchKernelGGL((gru_wave_kernel<40, float>), grid, dim3(64), 0, st, a);
+        else hipLaunchKernelGGL((gru_wave_kernel<40, __bf16>), grid, dim3(64), 0, st, a);
+        VC_HIP_CHECK(hipGetLastError());
+        return VC_OK;
+    }
     if (w_dtype == VC_F32) {
         VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_generic_kernel<float>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
