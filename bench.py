@@ -283,25 +283,19 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    import dist_util
+    rank, local, world = dist_util.env_world()
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU')
     torch.cuda.set_device(local)
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.distributed.init_process_group('nccl', device_id=torch.device('cuda', local))
+    dist_util.init('nccl')
 
     if args.workload == 'frontend':
         frames, dt, extra, cfg = bench_frontend(args, rank, world)
     else:
         frames, dt, extra, cfg = bench_full(args, rank, world)
 
-    t = torch.tensor([dt], dtype=torch.float64, device='cuda')
-    if world > 1:
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = dist_util.max_over_ranks(dt, device='cuda')
     if rank == 0:
         line = {'metric': 'mel frames/sec', 'value': round(frames * world * args.steps / dt, 1), 'unit': 'frames/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -313,8 +307,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline_frontend() if args.workload == 'frontend' else cpu_baseline_full()
         print(json.dumps(line))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    dist_util.finalize()
 
 
 if __name__ == '__main__':
