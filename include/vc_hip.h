@@ -186,6 +186,11 @@ typedef struct vc_gemm_desc {
     void* d_C;
     int32_t ldc;
     int32_t out_f32;
+    /* tf.layers.dropout in training mode (modules.py:292,294), applied after the activation:
+     * keep probability (0 = off) and the seed of the stateless mask (splitmix64 of the output
+     * element index m*ldc + column; see drop_keep_elem in csrc/vc_gemm.hip). */
+    float drop_keep;
+    unsigned long long drop_seed;
 } vc_gemm_desc;
 
 int vc_conv_gemm(const vc_gemm_desc* desc, void* stream);
@@ -209,6 +214,82 @@ size_t vc_gru_workspace_bytes(int32_t H, int32_t w_dtype);
 int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw, int32_t w_dtype,
                  int32_t n_seq, int32_t T, int32_t H, void* d_out, int32_t out_dtype,
                  void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training step of decoder_specs (/root/reference/decoder.py:185-263, 327-345), float32.
+ * Data gradients of dense/conv layers reuse vc_conv_gemm (dX = conv of dY with the taps flipped
+ * and the kernel in TF layout as the transposed operand).  The remaining pieces: */
+
+/* Filter gradient of tf.layers.dense / conv1d, written in TF layout [taps, Cin, N]:
+ *   dW[j*Cin + c, o] = sum_m X[m + j + shift0, c] * dY[m, o]    (shift0 = -pad_l; a frame of
+ *   another window contributes nothing).  Operands are TRANSPOSED, frames contiguous, built by
+ *   vc_transpose_pad with a zero margin of `margin` frames on both sides of every row:
+ *   d_XT [Cin, ldxt], d_dYT rows [N, ldyt]; both pointers address frame 0.  Groups = the banks. */
+typedef struct vc_wgrad_group {
+    const void* d_dYT;
+    void* d_dW;
+    int32_t N, taps, shift0;
+    int32_t ldw;        /* row stride of d_dW (0 = N): lets a group fill a column slice */
+} vc_wgrad_group;
+typedef struct vc_wgrad_desc {
+    const void* d_XT;
+    int32_t ldxt, ldyt, Cin, M, T, margin, n_groups;
+    vc_wgrad_group groups[VC_GEMM_MAX_GROUPS];
+} vc_wgrad_desc;
+int vc_conv_wgrad(const vc_wgrad_desc* desc, void* stream);
+
+/* XT[c, pad + m] = pro(X)[m + row_shift, c] (zero when the shifted frame leaves the window);
+ * pro = optional per-channel affine, relu, time max-pool (the forward operand prologue). */
+int vc_transpose_pad(const float* d_X, int32_t M, int32_t C, int32_t ld, int32_t T, const float* d_scale,
+                     const float* d_shift, int32_t relu, int32_t pool, int32_t row_shift, float* d_XT,
+                     int32_t ldt, int32_t pad, void* stream);
+
+/* Train-mode FusedBatchNorm bookkeeping (modules.py:77-84, is_training): batch mean / biased
+ * variance of X [M, C] -> scale/shift (consumed by the next launch's prologue or vc_affine_act),
+ * saved mean/rstd for backward, moving statistics updated in place (decay, Bessel-corrected
+ * variance).  d_workspace: vc_stats_workspace_floats(M, C) floats. */
+size_t vc_stats_workspace_floats(int32_t M, int32_t C);
+int vc_bn_train_stats(const float* d_X, int32_t M, int32_t C, int32_t ld, const float* d_gamma,
+                      const float* d_beta, float* d_moving_mean, float* d_moving_var, float decay, float eps,
+                      float* d_scale, float* d_shift, float* d_mean, float* d_rstd, float* d_workspace,
+                      void* stream);
+/* out = act(X * scale[c] + shift[c]) + R   (any of scale/shift/R may be NULL). */
+int vc_affine_act(const float* d_X, const float* d_scale, const float* d_shift, int32_t relu, const float* d_R,
+                  float* d_out, size_t n, int32_t C, void* stream);
+/* BatchNorm backward fused with what follows the norm: mode 0 none, 1 relu, 2 relu + time
+ * max-pool (modules.py:165,331: d_G is the gradient w.r.t. the pooled tensor).  Writes dX (raw
+ * conv output gradient), dgamma, dbeta. */
+int vc_bn_backward(const float* d_G, const float* d_X, int32_t M, int32_t C, int32_t ld, int32_t T,
+                   const float* d_gamma, const float* d_scale, const float* d_shift, const float* d_mean,
+                   const float* d_rstd, int32_t mode, float* d_dX, float* d_dgamma, float* d_dbeta,
+                   float* d_workspace, void* stream);
+/* dZ = (Y > 0) ? dY * inv_keep : 0 for Y = dropout(relu(Z)) (modules.py:291-294). */
+int vc_relu_dropout_backward(const float* d_dY, const float* d_Y, float inv_keep, float* d_dZ, size_t n, void* stream);
+/* highwaynet backward gate arithmetic (modules.py:315-318) on re-computed pre-activations in the
+ * forward's paired column layout [M, NP]; writes d(pre) [M, NP] and the direct path dO*(1-T). */
+int vc_highway_backward(const float* d_pre, int32_t NP, const float* d_X, const float* d_dO, int32_t M, int32_t H,
+                        float* d_dpre, float* d_dXd, void* stream);
+/* out[c] (+)= sum_m X[m, c]  (bias gradients). */
+int vc_col_sum(const float* d_X, int32_t M, int32_t C, int32_t ld, float* d_out, int32_t accumulate, void* stream);
+int vc_fill(float* d_p, float value, size_t n, void* stream);
+/* loss = weight * mean((y - t)^2) (decoder.py:187-189); optional d_dY = 2*weight/n * (y - t).
+ * y/t are contiguous [n/C, C]; d_dY is written with row stride ld_dy >= C (padding columns are
+ * left untouched).  d_workspace: 256 floats; d_loss: 1 float on the device (no host sync). */
+int vc_mse_loss(const float* d_y, const float* d_t, size_t n, float weight, float* d_dY, int32_t C, int32_t ld_dy,
+                float* d_loss, float* d_workspace, void* stream);
+/* tf.train.AdamOptimizer update on flat buffers (decoder.py:236-246): g is first multiplied by
+ * grad_scale (1/world for data-parallel averaging), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host,
+ * p -= lr_t * m / (sqrt(v) + epsilon). */
+int vc_adam_step(float* d_param, const float* d_grad, float* d_m, float* d_v, size_t n, float lr_t, float beta1,
+                 float beta2, float epsilon, float grad_scale, void* stream);
+/* GRU recurrence in training mode: like vc_gru_bidir (float32 weights) but also stores the gate
+ * activations d_gates [2][n_seq*T, 3H] (r | u | c) and r*h d_rh [2][n_seq*T, H]. */
+int vc_gru_train_forward(const float* d_xproj, const float* d_Wh_fw, const float* d_Wh_bw, int32_t n_seq,
+                         int32_t T, int32_t H, float* d_out, float* d_gates, float* d_rh, void* stream);
+/* BPTT of the above: d_dout [n_seq*T, 2H] -> d_dpre [n_seq*T, 6H] = gradient w.r.t. the gate
+ * pre-activations in the layout of d_xproj (input/recurrent weight gradients follow as GEMMs). */
+int vc_gru_backward(const float* d_dout, const float* d_out, const float* d_gates, const float* d_Wh_fw,
+                    const float* d_Wh_bw, int32_t n_seq, int32_t T, int32_t H, float* d_dpre, void* stream);
 
 /* float32 <-> bf16 conversion of a contiguous buffer (weights preparation, I/O). */
 int vc_convert(const void* d_src, int32_t src_dtype, void* d_dst, int32_t dst_dtype, size_t n, void* stream);

@@ -50,7 +50,20 @@ class GemmDesc(C.Structure):
                 ('pro_relu', C.c_int32), ('pro_pool', C.c_int32),
                 ('d_epi_scale', C.c_void_p), ('d_epi_shift', C.c_void_p), ('act', C.c_int32),
                 ('d_R', C.c_void_p), ('ldr', C.c_int32), ('d_C', C.c_void_p), ('ldc', C.c_int32),
-                ('out_f32', C.c_int32)]
+                ('out_f32', C.c_int32), ('drop_keep', C.c_float), ('drop_seed', C.c_ulonglong)]
+
+
+class WgradGroup(C.Structure):
+    """struct vc_wgrad_group (include/vc_hip.h)."""
+    _fields_ = [('d_dYT', C.c_void_p), ('d_dW', C.c_void_p), ('N', C.c_int32), ('taps', C.c_int32),
+                ('shift0', C.c_int32), ('ldw', C.c_int32)]
+
+
+class WgradDesc(C.Structure):
+    """struct vc_wgrad_desc (include/vc_hip.h)."""
+    _fields_ = [('d_XT', C.c_void_p), ('ldxt', C.c_int32), ('ldyt', C.c_int32), ('Cin', C.c_int32),
+                ('M', C.c_int32), ('T', C.c_int32), ('margin', C.c_int32), ('n_groups', C.c_int32),
+                ('groups', WgradGroup * GEMM_MAX_GROUPS)]
 
 
 _lib = None
@@ -80,6 +93,24 @@ _SIGS = {
     'vc_gru_bidir': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P,
                                C.c_size_t, _P]),
     'vc_convert': (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_size_t, _P]),
+    'vc_conv_wgrad': (C.c_int, [C.POINTER(WgradDesc), _P]),
+    'vc_transpose_pad': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32,
+                                   C.c_int32, _P, C.c_int32, C.c_int32, _P]),
+    'vc_stats_workspace_floats': (C.c_size_t, [C.c_int32, C.c_int32]),
+    'vc_bn_train_stats': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_float, C.c_float,
+                                    _P, _P, _P, _P, _P, _P]),
+    'vc_affine_act': (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_size_t, C.c_int32, _P]),
+    'vc_bn_backward': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P,
+                                 C.c_int32, _P, _P, _P, _P, _P]),
+    'vc_relu_dropout_backward': (C.c_int, [_P, _P, C.c_float, _P, C.c_size_t, _P]),
+    'vc_highway_backward': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    'vc_col_sum': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
+    'vc_fill': (C.c_int, [_P, C.c_float, C.c_size_t, _P]),
+    'vc_mse_loss': (C.c_int, [_P, _P, C.c_size_t, C.c_float, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    'vc_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
+                               C.c_float, _P]),
+    'vc_gru_train_forward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    'vc_gru_backward': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
 }
 
 

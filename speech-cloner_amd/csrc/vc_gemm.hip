@@ -58,8 +58,20 @@ struct KArgs {
     int32_t ldr;
     void* C;
     int32_t ldc, out_f32;
+    float drop_keep;               // 0 = no dropout, else keep probability (tf.layers.dropout, training)
+    unsigned long long drop_seed;
     KGroup g[VC_GEMM_MAX_GROUPS];
 };
+
+// Counter-based dropout mask: splitmix64 of (element index, seed); keep iff u24 < keep * 2^24.
+// Stateless, so tests can reproduce the mask on the host (tests/test_training_gpu.py).
+__device__ __forceinline__ bool drop_keep_elem(unsigned long long idx, unsigned long long seed, float keep) {
+    unsigned long long x = idx + seed * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return (float)(unsigned)(x >> 40) < keep * 16777216.0f;
+}
 
 __device__ __forceinline__ float act_fn(float v, int act) {
     switch (act) {
@@ -312,6 +324,8 @@ gemm_kernel(KArgs a) {
                     const int gm = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (gm >= a.M) continue;
                     float v = act_fn(acc[mi][ni][r] * s + b, a.act);
+                    if (a.drop_keep > 0.0f)
+                        v = drop_keep_elem((unsigned long long)gm * a.ldc + oc, a.drop_seed, a.drop_keep) ? v / a.drop_keep : 0.0f;
                     if (a.R) v += to_f32(reinterpret_cast<const T*>(a.R)[(size_t)gm * a.ldr + gn]);
                     store_out<T>(a.C, (size_t)gm * a.ldc + oc, v, a.out_f32);
                 }
@@ -527,6 +541,8 @@ conv_kernel(KArgs a) {
                 const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (gm >= a.M) continue;
                 float v = act_fn(acc[mi][ni][r] * sv + bv, a.act);
+                if (a.drop_keep > 0.0f)
+                    v = drop_keep_elem((unsigned long long)gm * a.ldc + oc, a.drop_seed, a.drop_keep) ? v / a.drop_keep : 0.0f;
                 if (a.R) v += to_f32(reinterpret_cast<const T*>(a.R)[(size_t)gm * a.ldr + gn]);
                 store_out<T>(a.C, (size_t)gm * a.ldc + oc, v, a.out_f32);
             }
@@ -545,6 +561,130 @@ template <typename T, int PRO> int launch_conv(const vc_gemm_desc* d, const KArg
     hipLaunchKernelGGL((conv_kernel<T, PRO>), dim3(ntm * ntn, d->n_groups), dim3(GEMM_THREADS), conv_lds_bytes(), st, ka);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------
+// Weight gradient: dW[j*Cin + c, o] = sum_m X[m + j + shift0, c] * dY[m, o]   (frames of other
+// windows excluded), i.e. the filter gradient of tf.layers.conv1d / dense, written straight in
+// TF layout [taps, Cin, Cout].  The reduction runs over frames, so both operands come
+// TRANSPOSED ([channels, frames], frames contiguous; vc_transpose_pad builds them with a zero
+// margin so shifted reads stay inside the allocation): A row r = (j, c) is XT row c read
+// (j + shift0) frames further along, B row o is dYT row o.  Same tiling / MFMA core as
+// gemm_kernel; the SAME-padding rule is a per-element select while staging.
+struct WGroup {
+    const void* dYT;    // [N, ldyt] rows of this group's output channels
+    void* dW;           // [taps*Cin, N] float32, row stride ldw
+    int32_t N, taps, shift0, ldw;
+};
+struct WArgs {
+    const void* XT;     // [Cin, ldxt], pointer at frame 0 (margin before it)
+    int32_t ldxt, ldyt, Cin, M, T, n_groups;
+    WGroup g[VC_GEMM_MAX_GROUPS];
+};
+
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+__global__ void __launch_bounds__(GEMM_THREADS, 2)
+wgrad_kernel(WArgs a) {
+    constexpr int MI = 2, BK = 32, BM = 128;
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, BUF_BYTES = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+    const WGroup grp = a.g[a.n_groups - 1 - (int)blockIdx.y];
+    const int R = grp.taps * a.Cin;
+    const int ntn = (grp.N + BN - 1) / BN, ntr = (R + BM - 1) / BM;
+    if ((int)blockIdx.x >= ntr * ntn) return;            // groups have different tile counts
+    const int rt = blockIdx.x / ntn, nt = blockIdx.x - rt * ntn;
+    const int r0 = rt * BM, n0 = nt * BN;
+    const int Tn = a.T, M = a.M;
+    const int nk = (M + BK - 1) / BK;
+    const float* XT = reinterpret_cast<const float*>(a.XT);
+    const float* YT = reinterpret_cast<const float*>(grp.dYT);
+
+    const int sc = tid & 7, sr = tid >> 3;
+    const float* a_base[4];
+    const float* b_base[4];
+    int a_dj[4];
+    bool a_ok[4], b_ok[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int r = r0 + sr + 32 * p;
+        a_ok[p] = r < R;
+        const int rr = min(r, R - 1);
+        const int j = rr / a.Cin, c = rr - j * a.Cin;
+        a_dj[p] = j + grp.shift0;
+        a_base[p] = XT + (size_t)c * a.ldxt + a_dj[p] + sc * 4;
+        const int n = n0 + sr + 32 * p;
+        b_ok[p] = n < grp.N;
+        b_base[p] = YT + (size_t)min(n, grp.N - 1) * a.ldyt + sc * 4;
+    }
+    f32x4 ra[4], rb[4];
+    int g_m = 0;                                          // first frame of the next slab to load
+    int st_m = 0;
+    auto gload = [&]() {
+        const int mm = min(g_m, max(M - 32, 0));          // keep the addresses inside the margin
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            ra[p] = *reinterpret_cast<const f32x4u*>(a_base[p] + mm);
+            rb[p] = *reinterpret_cast<const f32x4u*>(b_base[p] + mm);
+        }
+        st_m = g_m;
+        g_m += BK;
+    };
+    auto lstore = [&](int buf) {
+        char* As = smem + buf * BUF_BYTES;
+        char* Bs = As + A_BYTES;
+        const int m = st_m + sc * 4;
+        const bool exact = st_m <= max(M - 32, 0);        // clamped tail slab: treat as empty (M % 32 == 0 in practice)
+        const int t0 = m % Tn;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            f32x4 va = ra[p], vb = rb[p];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ts = t0 + e + a_dj[p];
+                const bool ok = exact && a_ok[p] && (m + e) < M && ts >= 0 && ts < Tn;
+                va[e] = ok ? va[e] : 0.0f;
+                vb[e] = (exact && b_ok[p] && (m + e) < M) ? vb[e] : 0.0f;
+            }
+            *reinterpret_cast<f32x4*>(As + (sr + 32 * p) * ROWB + sc * 16) = va;
+            *reinterpret_cast<f32x4*>(Bs + (sr + 32 * p) * ROWB + sc * 16) = vb;
+        }
+    };
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    gload();
+    lstore(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) gload();
+        const char* As = smem + (kt & 1) * BUF_BYTES;
+        Mma<float, MI>::slab(As, As + A_BYTES, wm, wn, lane, acc);
+        if (more) lstore((kt + 1) & 1);
+        __syncthreads();
+    }
+    const int i = lane & 31, h = lane >> 5;
+    float* dW = reinterpret_cast<float*>(grp.dW);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int gn = n0 + wn * 64 + ni * 32 + i;
+        if (gn >= grp.N) continue;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gr = r0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (gr < R) dW[(size_t)gr * grp.ldw + gn] = acc[mi][ni][r];
+            }
+    }
 }
 
 template <typename T, int MODE, int MI, int PRO> int launch_one(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
@@ -612,6 +752,8 @@ extern "C" int vc_conv_gemm(const vc_gemm_desc* d, void* stream) {
     ka.pro_scale = d->d_pro_scale; ka.pro_shift = d->d_pro_shift; ka.pro_relu = d->pro_relu; ka.pro_pool = d->pro_pool;
     ka.epi_scale = d->d_epi_scale; ka.epi_shift = d->d_epi_shift; ka.act = d->act;
     ka.R = d->d_R; ka.ldr = d->ldr; ka.C = d->d_C; ka.ldc = d->ldc; ka.out_f32 = d->out_f32;
+    ka.drop_keep = d->drop_keep; ka.drop_seed = d->drop_seed;
+    VC_REQUIRE(d->drop_keep >= 0.0f && d->drop_keep <= 1.0f, "drop_keep must be in [0, 1]");
     for (int g = 0; g < d->n_groups; ++g) {
         const vc_gemm_group& gg = d->groups[g];
         VC_REQUIRE(gg.d_Bt != nullptr && (reinterpret_cast<uintptr_t>(gg.d_Bt) & 15) == 0, "group %d: Bt NULL or misaligned", g);
@@ -622,4 +764,34 @@ extern "C" int vc_conv_gemm(const vc_gemm_desc* d, void* stream) {
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
     return d->dtype == VC_F32 ? launch<float>(d, ka, st) : launch<__bf16>(d, ka, st);
+}
+
+extern "C" int vc_conv_wgrad(const vc_wgrad_desc* d, void* stream) {
+    VC_REQUIRE(d != nullptr && d->d_XT != nullptr, "NULL desc / XT");
+    VC_REQUIRE(d->Cin > 0 && d->M > 0 && d->T > 0 && d->M % d->T == 0 && d->T % 4 == 0, "bad shape Cin=%d M=%d T=%d", d->Cin, d->M, d->T);
+    VC_REQUIRE(d->M % 32 == 0, "M (%d) must be a multiple of 32", d->M);
+    VC_REQUIRE(d->n_groups >= 1 && d->n_groups <= VC_GEMM_MAX_GROUPS, "n_groups out of range");
+    VC_REQUIRE(d->margin >= 32, "operand margin must be >= 32 frames");
+    WArgs wa;
+    wa.XT = d->d_XT; wa.ldxt = d->ldxt; wa.ldyt = d->ldyt; wa.Cin = d->Cin; wa.M = d->M; wa.T = d->T; wa.n_groups = d->n_groups;
+    int max_tiles = 0;
+    for (int g = 0; g < d->n_groups; ++g) {
+        const vc_wgrad_group& gg = d->groups[g];
+        VC_REQUIRE(gg.d_dYT && gg.d_dW && gg.N > 0 && gg.taps >= 1 && gg.taps <= 32, "group %d: bad arguments", g);
+        VC_REQUIRE(gg.shift0 > -d->margin && gg.shift0 + gg.taps - 1 < d->margin, "group %d: shift exceeds the margin", g);
+        wa.g[g].dYT = gg.d_dYT; wa.g[g].dW = gg.d_dW; wa.g[g].N = gg.N; wa.g[g].taps = gg.taps; wa.g[g].shift0 = gg.shift0;
+        wa.g[g].ldw = gg.ldw > 0 ? gg.ldw : gg.N;
+        const int tiles = ((gg.taps * d->Cin + 127) / 128) * ((gg.N + BN - 1) / BN);
+        if (tiles > max_tiles) max_tiles = tiles;
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2)));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wgrad_kernel, dim3(max_tiles, d->n_groups), dim3(GEMM_THREADS), lds_bytes(2),
+                       static_cast<hipStream_t>(stream), wa);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
 }

@@ -1,0 +1,570 @@
+// Training-step kernels for the decoder (/root/reference/decoder.py:185-263, 327-345) that are
+// not GEMMs: batch statistics + train-mode FusedBatchNorm (modules.py:39-102), its backward fused
+// with ReLU / max-pool backward, highway gate backward (modules.py:297-319), transposes that feed
+// the weight-gradient GEMM, MSE loss + gradient (decoder.py:187-195), bias gradients, the
+// TF-style Adam update (decoder.py:236-246) on one flat parameter buffer, and the GRU forward
+// (with saved gates) / BPTT recurrences (modules.py:168-204).  Contract: include/vc_hip.h.
+// Activations here are float32 (the reference trains in float32).
+#include <hip/hip_runtime.h>
+
+#include "vc_common.h"
+
+namespace {
+
+constexpr int TB = 256;
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// ---------------------------------------------------------------------------- column statistics
+// X [M, C] (row stride ld) -> partial sums over row blocks: part[blk][2][C].  Deterministic:
+// fixed row partition, fixed summation order; the finalize kernel adds the blocks in order.
+__global__ void __launch_bounds__(TB)
+col_stats_partial_kernel(const float* X, int M, int C, int ld, int rows_per_blk, float* part) {
+    const int c = blockIdx.x * TB + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
+    float s = 0.0f, q = 0.0f;
+    for (int r = r0; r < r1; ++r) {
+        const float v = X[(size_t)r * ld + c];
+        s += v;
+        q = fmaf(v, v, q);
+    }
+    part[((size_t)blockIdx.y * 2 + 0) * C + c] = s;
+    part[((size_t)blockIdx.y * 2 + 1) * C + c] = q;
+}
+
+// Train-mode batch norm bookkeeping: batch mean / biased variance -> scale, shift for the
+// consumer's prologue, saved mean / rstd for backward, moving statistics updated in place with
+// the Bessel-corrected variance (tf.nn.fused_batch_norm semantics), decay 0.999, eps 1e-3.
+__global__ void __launch_bounds__(TB)
+bn_train_finalize_kernel(const float* part, int nblk, int M, int C, const float* gamma, const float* beta,
+                         float* moving_mean, float* moving_var, float decay, float eps,
+                         float* scale, float* shift, float* mean_out, float* rstd_out) {
+    const int c = blockIdx.x * TB + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)part[((size_t)b * 2 + 0) * C + c];
+        q += (double)part[((size_t)b * 2 + 1) * C + c];
+    }
+    const double mean = s / M;
+    double var = q / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float sc = gamma[c] * rstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    mean_out[c] = (float)mean;
+    rstd_out[c] = rstd;
+    if (moving_mean) {
+        const double unb = var * ((double)M / (double)(M > 1 ? M - 1 : 1));
+        moving_mean[c] = moving_mean[c] * decay + (float)mean * (1.0f - decay);
+        moving_var[c] = moving_var[c] * decay + (float)unb * (1.0f - decay);
+    }
+}
+
+// out = act(X * scale[c] + shift[c]) + R      (BatchNorm apply + residual, modules.py:338-340)
+__global__ void __launch_bounds__(TB)
+affine_act_kernel(const float* X, const float* scale, const float* shift, int relu, const float* R, float* out,
+                  size_t n, int C) {
+    size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * TB;
+    for (; i < n; i += stride) {
+        const int c = (int)(i % C);
+        float v = X[i] * (scale ? scale[c] : 1.0f) + (shift ? shift[c] : 0.0f);
+        if (relu) v = fmaxf(v, 0.0f);
+        if (R) v += R[i];
+        out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------- BN backward
+// Upstream gradient G is w.r.t.  Y = post(bn(X)) where post = identity | relu | pool(relu):
+//   mode 0: dBN = G
+//   mode 1: dBN = G * [bn(X) > 0]                                            (relu)
+//   mode 2: G is w.r.t. the max-pooled relu output P[t] = max(A[t], A[t+1]) (last frame: A[t]):
+//           dA[t] = G[t]*[t==T-1 or A[t] >= A[t+1]] + G[t-1]*[t>0 and A[t] > A[t-1]],  dBN = dA*[A>0]
+__device__ __forceinline__ float bn_upstream(const float* G, const float* X, int ld, size_t row, int c, int t, int T,
+                                             float sc, float sh, int mode) {
+    const size_t i = row * ld + c;
+    if (mode == 0) return G[i];
+    const float a = fmaxf(X[i] * sc + sh, 0.0f);
+    if (mode == 1) return a > 0.0f ? G[i] : 0.0f;
+    float g = 0.0f;
+    if (a > 0.0f) {
+        if (t == T - 1) g += G[i];
+        else {
+            const float an = fmaxf(X[i + ld] * sc + sh, 0.0f);
+            if (a >= an) g += G[i];
+        }
+        if (t > 0) {
+            const float ap = fmaxf(X[i - ld] * sc + sh, 0.0f);
+            if (a > ap) g += G[i - ld];
+        }
+    }
+    return g;
+}
+
+// partial column sums of dBN and dBN * xhat
+__global__ void __launch_bounds__(TB)
+bn_bwd_partial_kernel(const float* G, const float* X, int M, int C, int ld, int T, const float* scale,
+                      const float* shift, const float* mean, const float* rstd, int mode, int rows_per_blk,
+                      float* part) {
+    const int c = blockIdx.x * TB + threadIdx.x;
+    if (c >= C) return;
+    const int r0 = blockIdx.y * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
+    const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
+    float s = 0.0f, q = 0.0f;
+    for (int r = r0; r < r1; ++r) {
+        const float d = bn_upstream(G, X, ld, r, c, r % T, T, sc, sh, mode);
+        const float xh = (X[(size_t)r * ld + c] - mu) * rs;
+        s += d;
+        q = fmaf(d, xh, q);
+    }
+    part[((size_t)blockIdx.y * 2 + 0) * C + c] = s;
+    part[((size_t)blockIdx.y * 2 + 1) * C + c] = q;
+}
+
+// reduce partials -> dbeta, dgamma ; dX = gamma*rstd*(dBN - dbeta/M - xhat*dgamma/M)
+__global__ void __launch_bounds__(TB)
+bn_bwd_reduce_kernel(const float* part, int nblk, int C, float* dbeta, float* dgamma) {
+    const int c = blockIdx.x * TB + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)part[((size_t)b * 2 + 0) * C + c];
+        q += (double)part[((size_t)b * 2 + 1) * C + c];
+    }
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+}
+
+__global__ void __launch_bounds__(TB)
+bn_bwd_apply_kernel(const float* G, const float* X, int M, int C, int ld, int T, const float* gamma,
+                    const float* scale, const float* shift, const float* mean, const float* rstd,
+                    const float* dbeta, const float* dgamma, int mode, float* dX) {
+    const size_t n = (size_t)M * C;
+    size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * TB;
+    const float invM = 1.0f / (float)M;
+    for (; i < n; i += stride) {
+        const size_t r = i / C;
+        const int c = (int)(i - r * C);
+        const float d = bn_upstream(G, X, ld, r, c, (int)(r % T), T, scale[c], shift[c], mode);
+        const float xh = (X[r * ld + c] - mean[c]) * rstd[c];
+        dX[r * ld + c] = gamma[c] * rstd[c] * (d - dbeta[c] * invM - xh * dgamma[c] * invM);
+    }
+}
+
+// ---------------------------------------------------------------------------- relu/dropout bwd
+// Y = dropout(relu(z)) is stored; dz = (Y > 0) ? dY * inv_keep : 0   (inv_keep = 1 without dropout)
+__global__ void __launch_bounds__(TB)
+relu_drop_bwd_kernel(const float* dY, const float* Y, float inv_keep, float* dZ, size_t n) {
+    size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * TB;
+    for (; i < n; i += stride) dZ[i] = Y[i] > 0.0f ? dY[i] * inv_keep : 0.0f;
+}
+
+// ---------------------------------------------------------------------------- highway backward
+// pre [M, NP] holds the re-computed pre-activations in the paired layout of the forward kernel
+// (per 64 columns: 32 x dense1 | 32 x dense2, bias included).  With h = relu(ph), t = sig(pt):
+//   out = h t + x (1 - t)
+//   dpre_h = dO * t * [ph > 0] ; dpre_t = dO * (h - x) * t (1 - t) ; dx_direct = dO * (1 - t)
+__global__ void __launch_bounds__(TB)
+highway_bwd_kernel(const float* pre, int NP, const float* X, const float* dO, int M, int H, float* dpre, float* dXd) {
+    const size_t n = (size_t)M * H;
+    size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * TB;
+    for (; i < n; i += stride) {
+        const size_t r = i / H;
+        const int j = (int)(i - r * H);
+        const int ch = 64 * (j >> 5) + (j & 31), ct = ch + 32;
+        const float ph = pre[r * NP + ch], pt = pre[r * NP + ct];
+        const float h = fmaxf(ph, 0.0f), t = sigmoidf_(pt);
+        const float g = dO[i], x = X[i];
+        dpre[r * NP + ch] = ph > 0.0f ? g * t : 0.0f;
+        dpre[r * NP + ct] = g * (h - x) * t * (1.0f - t);
+        dXd[i] = g * (1.0f - t);
+    }
+}
+
+// zero the padding columns of a paired-layout gradient buffer (units >= H inside the last 64-block)
+__global__ void __launch_bounds__(TB)
+fill_kernel(float* p, float v, size_t n) {
+    size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * TB;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------- transpose (+prologue)
+// X [M, C] (ld) -> XT [C, ldt] at column offset `pad`:  XT[c][pad + m] = pro(X)[m][c]
+//   pro: optional per-channel affine, relu, time max-pool (same rule as the forward operand load),
+//   optional row shift by `shift` frames inside each window (zero where the source leaves it)
+//   -- the latter builds h_{t-1} / h_{t+1} for the recurrent weight gradients.
+__global__ void __launch_bounds__(TB)
+transpose_pad_kernel(const float* X, int M, int C, int ld, int T, const float* scale, const float* shiftv, int relu,
+                     int pool, int row_shift, float* XT, int ldt, int pad) {
+    __shared__ float tile[32][33];
+    const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int m = m0 + k, c = c0 + tx;
+        float v = 0.0f;
+        if (m < M && c < C) {
+            const int t = m % T;
+            const int ts = t + row_shift;
+            if (ts >= 0 && ts < T) {
+                const size_t i = (size_t)(m + row_shift) * ld + c;
+                const float sc = scale ? scale[c] : 1.0f, sh = shiftv ? shiftv[c] : 0.0f;
+                v = X[i] * sc + sh;
+                if (relu) v = fmaxf(v, 0.0f);
+                if (pool && ts + 1 < T) {
+                    float v2 = X[i + ld] * sc + sh;
+                    if (relu) v2 = fmaxf(v2, 0.0f);
+                    v = fmaxf(v, v2);
+                }
+            }
+        }
+        tile[k][tx] = v;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, m = m0 + tx;
+        if (c < C && m < M) XT[(size_t)c * ldt + pad + m] = tile[tx][k];
+    }
+}
+
+// column sums (bias gradients): out[c] (+)= sum_m X[m][c]
+__global__ void __launch_bounds__(TB)
+col_sum_kernel(const float* X, int M, int C, int ld, float* out, int accumulate) {
+    const int c = blockIdx.x * TB + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int r = 0; r < M; ++r) s += (double)X[(size_t)r * ld + c];
+    out[c] = (accumulate ? out[c] : 0.0f) + (float)s;
+}
+
+// ---------------------------------------------------------------------------- loss
+// loss = w * mean((y - t)^2) ; dY = 2 w / n * (y - t).  One block -> one partial (deterministic
+// second pass on the host side of the ABI: partials are summed in order by loss_final_kernel).
+__global__ void __launch_bounds__(TB)
+mse_partial_kernel(const float* y, const float* t, size_t n, float w, float* dY, int C, int ld, float* part) {
+    __shared__ float red[TB / 64];
+    const float g = 2.0f * w / (float)n;
+    float s = 0.0f;
+    for (size_t i = (size_t)blockIdx.x * TB + threadIdx.x; i < n; i += (size_t)gridDim.x * TB) {
+        const float d = y[i] - t[i];
+        s = fmaf(d, d, s);
+        if (dY) dY[(i / C) * ld + (i % C)] = g * d;
+    }
+    s = vc::wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+__global__ void loss_final_kernel(const float* part, int nblk, size_t n, float w, float* out) {
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[b];
+    out[0] = (float)((double)w * s / (double)n);
+}
+
+// ---------------------------------------------------------------------------- Adam
+// tf.train.AdamOptimizer (decoder.py:236-246): lr_t = lr*sqrt(1-b2^t)/(1-b1^t) (host),
+// m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr_t * m / (sqrt(v) + eps)
+__global__ void __launch_bounds__(TB)
+adam_kernel(float* p, const float* g, float* m, float* v, size_t n, float lr_t, float b1, float b2, float eps,
+            float gscale) {
+    size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * TB;
+    for (; i < n; i += stride) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= lr_t * mi / (sqrtf(vi) + eps);
+    }
+}
+
+// ---------------------------------------------------------------------------- GRU (training)
+// Generic one-workgroup-per-(window, direction) recurrences in float32 with the weights read
+// through L2 (or LDS when they fit).  Forward saves r, u, c, r*h for the backward pass.
+struct GruTrainArgs {
+    const float* xproj;      // [n_seq*T, 6H]
+    const float* Wh[2];      // [H, 3H]
+    float* out;              // [n_seq*T, 2H]
+    float* gates;            // [2][n_seq*T, 3H]  r | u | c (post-activation)
+    float* rh;               // [2][n_seq*T, H]
+    int32_t n_seq, T, H;
+};
+
+__global__ void __launch_bounds__(512)
+gru_train_fwd_kernel(GruTrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.H, H3 = 3 * H, NT = blockDim.x, tid = threadIdx.x;
+    float* h = reinterpret_cast<float*>(smem);
+    float* rhs = h + H;
+    float* us = rhs + H;
+    const int seq = blockIdx.x, dir = blockIdx.y;
+    const float* W = a.Wh[dir];
+    const size_t MT = (size_t)a.n_seq * a.T;
+    float* gates = a.gates + (size_t)dir * MT * H3;
+    float* rhg = a.rh + (size_t)dir * MT * H;
+    for (int i = tid; i < H; i += NT) h[i] = 0.0f;
+    __syncthreads();
+    const size_t xrow = 6 * (size_t)H;
+    const float* xbase = a.xproj + (size_t)seq * a.T * xrow + (size_t)dir * H3;
+    int t = dir ? a.T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    for (int step = 0; step < a.T; ++step, t += dt) {
+        const size_t row = (size_t)seq * a.T + t;
+        for (int col = tid; col < 2 * H; col += NT) {
+            float acc = xbase[(size_t)t * xrow + col];
+            for (int k = 0; k < H; ++k) acc = fmaf(h[k], W[(size_t)k * H3 + col], acc);
+            const float g = sigmoidf_(acc);
+            gates[row * H3 + col] = g;
+            if (col < H) { const float v = g * h[col]; rhs[col] = v; rhg[row * H + col] = v; }
+            else us[col - H] = g;
+        }
+        __syncthreads();
+        float hn = 0.0f;
+        for (int col = tid; col < H; col += NT) {
+            float acc = xbase[(size_t)t * xrow + 2 * H + col];
+            for (int k = 0; k < H; ++k) acc = fmaf(rhs[k], W[(size_t)k * H3 + 2 * H + col], acc);
+            const float c = tanhf(acc);
+            gates[row * H3 + 2 * H + col] = c;
+            const float u = us[col];
+            hn = u * h[col] + (1.0f - u) * c;
+            a.out[row * 2 * H + (size_t)dir * H + col] = hn;
+        }
+        __syncthreads();
+        for (int col = tid; col < H; col += NT) h[col] = a.out[row * 2 * H + (size_t)dir * H + col];
+        __syncthreads();
+    }
+}
+
+struct GruBwdArgs {
+    const float* dout;       // [n_seq*T, 2H]   gradient w.r.t. the GRU output
+    const float* out;        // [n_seq*T, 2H]   forward output (h_t)
+    const float* gates;      // [2][n_seq*T, 3H]
+    const float* Wh[2];      // [H, 3H]
+    float* dpre;             // [n_seq*T, 6H]   d(pre-activation) r | u | c per direction (same layout as xproj)
+    int32_t n_seq, T, H;
+};
+
+// BPTT: runs each direction's time loop in reverse.  Per step (h = h_{t-1} in that direction):
+//   dh += dout_t ; du = dh (h - c) ; dc = dh (1 - u) ; dh_prev = dh u
+//   dc_pre = dc (1 - c^2) ; d(rh) = Wc_h dc_pre ; dr = d(rh) h ; dh_prev += d(rh) r
+//   dr_pre = dr r (1-r) ; du_pre = du u (1-u) ; dh_prev += Wg_h [dr_pre ; du_pre]
+__global__ void __launch_bounds__(512)
+gru_bwd_kernel(GruBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.H, H3 = 3 * H, NT = blockDim.x, tid = threadIdx.x;
+    float* dh = reinterpret_cast<float*>(smem);     // [H] carried gradient
+    float* dcp = dh + H;                            // [H] dc_pre
+    float* dgp = dcp + H;                           // [2H] dr_pre | du_pre
+    float* drh = dgp + 2 * H;                       // [H]
+    const int seq = blockIdx.x, dir = blockIdx.y;
+    const float* W = a.Wh[dir];
+    const size_t MT = (size_t)a.n_seq * a.T;
+    const float* gates = a.gates + (size_t)dir * MT * H3;
+    for (int i = tid; i < H; i += NT) dh[i] = 0.0f;
+    __syncthreads();
+    // forward order was t0, t0+dt, ...; walk it backwards
+    int t = dir ? 0 : a.T - 1;
+    const int dtb = dir ? 1 : -1;                   // towards the forward pass's start
+    for (int step = 0; step < a.T; ++step, t += dtb) {
+        const size_t row = (size_t)seq * a.T + t;
+        const bool first = (step == a.T - 1);       // forward's first step: h_prev = 0
+        const size_t prow = row + dtb;              // row of h_{prev} in forward order
+        // stage 1: elementwise through h' = u h + (1-u) c
+        for (int j = tid; j < H; j += NT) {
+            const float g = dh[j] + a.dout[row * 2 * H + (size_t)dir * H + j];
+            const float u = gates[row * H3 + H + j], c = gates[row * H3 + 2 * H + j];
+            const float hp = first ? 0.0f : a.out[prow * 2 * H + (size_t)dir * H + j];
+            const float du = g * (hp - c);
+            const float dc = g * (1.0f - u);
+            dcp[j] = dc * (1.0f - c * c);
+            dgp[H + j] = du * u * (1.0f - u);
+            dh[j] = g * u;                           // dh_prev, part 1
+        }
+        __syncthreads();
+        // stage 2: d(rh) = Wc_h @ dc_pre  (Wc_h = W[:, 2H:3H], rows = rh index)
+        for (int k = tid; k < H; k += NT) {
+            float acc = 0.0f;
+            const float* w = W + (size_t)k * H3 + 2 * H;
+            for (int j = 0; j < H; ++j) acc = fmaf(w[j], dcp[j], acc);
+            drh[k] = acc;
+        }
+        __syncthreads();
+        for (int j = tid; j < H; j += NT) {
+            const float r = gates[row * H3 + j];
+            const float hp = first ? 0.0f : a.out[prow * 2 * H + (size_t)dir * H + j];
+            const float dr = drh[j] * hp;
+            dgp[j] = dr * r * (1.0f - r);
+            dh[j] += drh[j] * r;
+        }
+        __syncthreads();
+        // stage 3: dh_prev += Wg_h @ [dr_pre ; du_pre]
+        for (int k = tid; k < H; k += NT) {
+            float acc = 0.0f;
+            const float* w = W + (size_t)k * H3;
+            for (int j = 0; j < 2 * H; ++j) acc = fmaf(w[j], dgp[j], acc);
+            dh[k] += acc;
+        }
+        // write pre-activation gradients in xproj layout
+        float* dp = a.dpre + row * 6 * (size_t)H + (size_t)dir * H3;
+        for (int j = tid; j < 2 * H; j += NT) dp[j] = dgp[j];
+        for (int j = tid; j < H; j += NT) dp[2 * H + j] = dcp[j];
+        __syncthreads();
+    }
+}
+
+inline int nblocks(size_t n) {
+    size_t b = (n + TB - 1) / TB;
+    return (int)(b < 8192 ? (b ? b : 1) : 8192);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t vc_stats_workspace_floats(int32_t M, int32_t C) {
+    const int rows = 256;
+    const int nblk = (M + rows - 1) / rows;
+    return (size_t)nblk * 2 * C;
+}
+
+int vc_bn_train_stats(const float* d_X, int32_t M, int32_t C, int32_t ld, const float* d_gamma, const float* d_beta,
+                      float* d_moving_mean, float* d_moving_var, float decay, float eps, float* d_scale,
+                      float* d_shift, float* d_mean, float* d_rstd, float* d_workspace, void* stream) {
+    VC_REQUIRE(d_X && d_gamma && d_beta && d_scale && d_shift && d_mean && d_rstd && d_workspace, "NULL argument");
+    VC_REQUIRE(M > 0 && C > 0 && ld >= C, "bad shape");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rows = 256, nblk = (M + rows - 1) / rows;
+    hipLaunchKernelGGL(col_stats_partial_kernel, dim3((C + TB - 1) / TB, nblk), dim3(TB), 0, st, d_X, M, C, ld, rows, d_workspace);
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((C + TB - 1) / TB), dim3(TB), 0, st, d_workspace, nblk, M, C, d_gamma,
+                       d_beta, d_moving_mean, d_moving_var, decay, eps, d_scale, d_shift, d_mean, d_rstd);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_affine_act(const float* d_X, const float* d_scale, const float* d_shift, int32_t relu, const float* d_R,
+                  float* d_out, size_t n, int32_t C, void* stream) {
+    VC_REQUIRE(d_X && d_out && C > 0, "bad argument");
+    hipLaunchKernelGGL(affine_act_kernel, dim3(nblocks(n)), dim3(TB), 0, static_cast<hipStream_t>(stream), d_X, d_scale,
+                       d_shift, relu, d_R, d_out, n, C);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_bn_backward(const float* d_G, const float* d_X, int32_t M, int32_t C, int32_t ld, int32_t T, const float* d_gamma,
+                   const float* d_scale, const float* d_shift, const float* d_mean, const float* d_rstd, int32_t mode,
+                   float* d_dX, float* d_dgamma, float* d_dbeta, float* d_workspace, void* stream) {
+    VC_REQUIRE(d_G && d_X && d_gamma && d_scale && d_shift && d_mean && d_rstd && d_dX && d_dgamma && d_dbeta && d_workspace,
+               "NULL argument");
+    VC_REQUIRE(M > 0 && C > 0 && ld >= C && T > 0 && M % T == 0 && mode >= 0 && mode <= 2, "bad shape/mode");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int rows = 256, nblk = (M + rows - 1) / rows;
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((C + TB - 1) / TB, nblk), dim3(TB), 0, st, d_G, d_X, M, C, ld, T, d_scale,
+                       d_shift, d_mean, d_rstd, mode, rows, d_workspace);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + TB - 1) / TB), dim3(TB), 0, st, d_workspace, nblk, C, d_dbeta, d_dgamma);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks((size_t)M * C)), dim3(TB), 0, st, d_G, d_X, M, C, ld, T, d_gamma,
+                       d_scale, d_shift, d_mean, d_rstd, d_dbeta, d_dgamma, mode, d_dX);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_relu_dropout_backward(const float* d_dY, const float* d_Y, float inv_keep, float* d_dZ, size_t n, void* stream) {
+    VC_REQUIRE(d_dY && d_Y && d_dZ, "NULL argument");
+    hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(nblocks(n)), dim3(TB), 0, static_cast<hipStream_t>(stream), d_dY, d_Y,
+                       inv_keep, d_dZ, n);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_highway_backward(const float* d_pre, int32_t NP, const float* d_X, const float* d_dO, int32_t M, int32_t H,
+                        float* d_dpre, float* d_dXd, void* stream) {
+    VC_REQUIRE(d_pre && d_X && d_dO && d_dpre && d_dXd, "NULL argument");
+    VC_REQUIRE(NP == 64 * ((H + 31) / 32), "NP must be the paired width 64*ceil(H/32)");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (NP != 2 * H) hipLaunchKernelGGL(fill_kernel, dim3(nblocks((size_t)M * NP)), dim3(TB), 0, st, d_dpre, 0.0f, (size_t)M * NP);
+    hipLaunchKernelGGL(highway_bwd_kernel, dim3(nblocks((size_t)M * H)), dim3(TB), 0, st, d_pre, NP, d_X, d_dO, M, H, d_dpre, d_dXd);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_transpose_pad(const float* d_X, int32_t M, int32_t C, int32_t ld, int32_t T, const float* d_scale,
+                     const float* d_shift, int32_t relu, int32_t pool, int32_t row_shift, float* d_XT, int32_t ldt,
+                     int32_t pad, void* stream) {
+    VC_REQUIRE(d_X && d_XT, "NULL argument");
+    VC_REQUIRE(M > 0 && C > 0 && ld >= C && T > 0 && ldt >= M + 2 * pad && pad >= 0, "bad shape");
+    VC_REQUIRE(!(d_scale == nullptr) == !(d_shift == nullptr), "scale and shift go together");
+    hipLaunchKernelGGL(transpose_pad_kernel, dim3((M + 31) / 32, (C + 31) / 32), dim3(TB), 0, static_cast<hipStream_t>(stream),
+                       d_X, M, C, ld, T, d_scale, d_shift, relu, pool, row_shift, d_XT, ldt, pad);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_col_sum(const float* d_X, int32_t M, int32_t C, int32_t ld, float* d_out, int32_t accumulate, void* stream) {
+    VC_REQUIRE(d_X && d_out && M > 0 && C > 0 && ld >= C, "bad argument");
+    hipLaunchKernelGGL(col_sum_kernel, dim3((C + TB - 1) / TB), dim3(TB), 0, static_cast<hipStream_t>(stream), d_X, M, C, ld,
+                       d_out, accumulate);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_fill(float* d_p, float value, size_t n, void* stream) {
+    VC_REQUIRE(d_p, "NULL argument");
+    if (n) hipLaunchKernelGGL(fill_kernel, dim3(nblocks(n)), dim3(TB), 0, static_cast<hipStream_t>(stream), d_p, value, n);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_mse_loss(const float* d_y, const float* d_t, size_t n, float weight, float* d_dY, int32_t C, int32_t ld_dy,
+                float* d_loss, float* d_workspace, void* stream) {
+    VC_REQUIRE(d_y && d_t && d_loss && d_workspace && n > 0 && C > 0 && ld_dy >= C, "bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nb = 256;
+    hipLaunchKernelGGL(mse_partial_kernel, dim3(nb), dim3(TB), 0, st, d_y, d_t, n, weight, d_dY, C, ld_dy, d_workspace);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(1), 0, st, d_workspace, nb, n, weight, d_loss);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_adam_step(float* d_param, const float* d_grad, float* d_m, float* d_v, size_t n, float lr_t, float beta1,
+                 float beta2, float epsilon, float grad_scale, void* stream) {
+    VC_REQUIRE(d_param && d_grad && d_m && d_v, "NULL argument");
+    if (n) hipLaunchKernelGGL(adam_kernel, dim3(nblocks(n)), dim3(TB), 0, static_cast<hipStream_t>(stream), d_param, d_grad,
+                              d_m, d_v, n, lr_t, beta1, beta2, epsilon, grad_scale);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_gru_train_forward(const float* d_xproj, const float* d_Wh_fw, const float* d_Wh_bw, int32_t n_seq, int32_t T,
+                         int32_t H, float* d_out, float* d_gates, float* d_rh, void* stream) {
+    VC_REQUIRE(d_xproj && d_Wh_fw && d_Wh_bw && d_out && d_gates && d_rh, "NULL argument");
+    VC_REQUIRE(n_seq > 0 && T > 0 && H > 0 && H <= 1024, "bad shape");
+    GruTrainArgs a;
+    a.xproj = d_xproj; a.Wh[0] = d_Wh_fw; a.Wh[1] = d_Wh_bw; a.out = d_out; a.gates = d_gates; a.rh = d_rh;
+    a.n_seq = n_seq; a.T = T; a.H = H;
+    const int nt = H >= 128 ? 512 : 256;
+    hipLaunchKernelGGL(gru_train_fwd_kernel, dim3(n_seq, 2), dim3(nt), 3 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_gru_backward(const float* d_dout, const float* d_out, const float* d_gates, const float* d_Wh_fw,
+                    const float* d_Wh_bw, int32_t n_seq, int32_t T, int32_t H, float* d_dpre, void* stream) {
+    VC_REQUIRE(d_dout && d_out && d_gates && d_Wh_fw && d_Wh_bw && d_dpre, "NULL argument");
+    VC_REQUIRE(n_seq > 0 && T > 0 && H > 0 && H <= 1024, "bad shape");
+    GruBwdArgs a;
+    a.dout = d_dout; a.out = d_out; a.gates = d_gates; a.Wh[0] = d_Wh_fw; a.Wh[1] = d_Wh_bw; a.dpre = d_dpre;
+    a.n_seq = n_seq; a.T = T; a.H = H;
+    const int nt = H >= 128 ? 512 : 256;
+    hipLaunchKernelGGL(gru_bwd_kernel, dim3(n_seq, 2), dim3(nt), 5 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+}  // extern "C"

@@ -158,6 +158,11 @@ class decoder_specs:
         if self.encoder is not None:
             d.update(self.encoder.opt_state)
         d.update(self.opt_state)
+        tr = getattr(self, '_trainer', None)
+        if tr is not None:                            # Adam slots under TF's names (dec_opt/<var>/Adam[_1])
+            for n, (m, v) in tr.adam_slots().items():
+                d['dec_opt/' + n + '/Adam'] = m.cpu().numpy()
+                d['dec_opt/' + n + '/Adam_1'] = v.cpu().numpy()
         return d
 
     def save(self, save_path=None, i_checkpoint=None, verbose=True):
@@ -276,10 +281,79 @@ class decoder_specs:
                 i_batch, np.mean(loss_v), np.mean(mel_loss_v), np.mean(stft_loss_v)))
         return np.mean(loss_v), np.mean(mel_loss_v), np.mean(stft_loss_v)
 
+    # --------------------------------------------------------------------------- training
+    def _get_trainer(self):
+        if not self.cfg_d['is_training']:
+            raise Exception('Model is not in training model')
+        if getattr(self, '_trainer', None) is None:
+            import training
+            self._trainer = training.DecoderTrainer(self)
+        return self._trainer
+
     def exec_train_step(self, inputs, target_mel, target_stft):
-        raise NotImplementedError(' - ERROR, decoder training step: backward kernels are not built yet '
-                                  '(BASELINE config 5; see DESIGN.md)')
+        """decoder.py:327-345: forward + backward + Adam on one batch (this rank's batch under data
+        parallelism; gradients are averaged over ranks with an RCCL all-reduce).  Returns
+        (mel_loss, stft_loss, loss, global_step, train_step) -- train_step is None (a TF op)."""
+        import torch
+        c = self.cfg_d
+        tr = self._get_trainer()
+        x = self._to_device(inputs, self._input_width(), 'decoder input')
+        tm = self._to_device(target_mel, c['steps_v'][0]['n_output'], 'target_mel')
+        ts = self._to_device(target_stft, c['steps_v'][1]['n_output'], 'target_stft')
+        losses = tr.forward_backward(x, tm, ts)
+        world = torch.distributed.get_world_size() if (torch.distributed.is_available() and
+                                                        torch.distributed.is_initialized()) else 1
+        global_step = tr.apply_gradients(world)
+        mel_loss, stft_loss = (np.float32(v) for v in losses.cpu().numpy())
+        if c['loss_type'] == 'log':
+            loss = np.float32(np.log(mel_loss) + np.log(stft_loss))
+        else:
+            loss = np.float32(mel_loss + stft_loss)
+        self.i_global_step = global_step
+        return (mel_loss, stft_loss, loss, np.int32(global_step), None)
+
+    def _lr_decay(self):
+        """decoder.py:248: lr = lr_start / (1 + decay * epoch)."""
+        o = self.opt_state
+        o['dec_opt/learning_rate'] = np.float32(float(o['dec_opt/learning_rate_start']) /
+                                                (1.0 + float(o['dec_opt/learning_rate_decay']) * float(o['dec_opt/epoch'])))
+        return o['dec_opt/learning_rate']
 
     def train(self):
-        raise NotImplementedError(' - ERROR, decoder training loop: backward kernels are not built yet '
-                                  '(BASELINE config 5; see DESIGN.md)')
+        """decoder.py:379-444 (same prints and control flow; needs a dataset object providing
+        get_n_windows / spec_window_sampler, which this package does not ship)."""
+        add_pams = {}
+        if 'ds_filter_d' in self.cfg_d.keys():
+            add_pams['ds_filter_d'] = self.cfg_d['ds_filter_d']
+        self.cfg_d['n_samples_trn'] = self.ds.get_n_windows(self.cfg_d['ds_prop_val'], **add_pams)[0]
+        self.sampler_trn = self.ds.spec_window_sampler(batch_size=self.cfg_d['batch_size'], n_epochs=99999999,
+                                                       randomize_samples=self.cfg_d['randomize_samples'],
+                                                       sample_trn=True, prop_val=self.cfg_d['ds_prop_val'], **add_pams)
+        self.sampler_val = self.ds.spec_window_sampler(batch_size=self.cfg_d['batch_size'], n_epochs=99999999,
+                                                       randomize_samples=self.cfg_d['randomize_samples'],
+                                                       sample_trn=False, prop_val=self.cfg_d['ds_prop_val'], **add_pams)
+        self.cfg_d['n_steps_epoch_trn'] = self.cfg_d['n_samples_trn'] // self.cfg_d['batch_size']
+        self.iter_val = iter(self.sampler_val)
+        print(' Starting Training ...')
+        print(' n_samples_trn:    ', self.cfg_d['n_samples_trn'])
+        print(' n_steps_epoch_trn:', self.cfg_d['n_steps_epoch_trn'])
+        print(' batch_size:       ', self.cfg_d['batch_size'])
+        print(' n_epochs:         ', self.cfg_d['n_epochs'])
+        input('Press --ENTER--')
+        self.i_epoch = int(self.opt_state['dec_opt/epoch'])
+        self.lr = self._lr_decay()
+        for mfcc_trn, mel_trn, stft_trn in self.sampler_trn:
+            mel_loss_trn, stft_loss_trn, loss_trn, global_step, train_step = self.exec_train_step(mfcc_trn, mel_trn, stft_trn)
+            print(' - i_epoch={}   global_step={}   mel_loss_trn={:6.3f}  stft_loss_trn={:6.3f}  loss_trn={:6.3f}'.format(
+                self.i_epoch, global_step, mel_loss_trn, stft_loss_trn, loss_trn))
+            if (global_step / self.cfg_d['n_steps_epoch_trn']) % self.cfg_d['save_each_n_epochs'] == 0:
+                print(' Saving, epoch={} ...'.format(self.i_epoch))
+                self.save()
+            if global_step % self.cfg_d['n_steps_epoch_trn'] == 0:
+                self.opt_state['dec_opt/epoch'] = np.int32(int(self.opt_state['dec_opt/epoch']) + 1)
+                self.i_epoch = int(self.opt_state['dec_opt/epoch'])
+                self.lr = self._lr_decay()
+                if self.i_epoch >= self.cfg_d['n_epochs']:
+                    break
+        print(' End of Training !!!')
+        return None

@@ -1,0 +1,473 @@
+"""Decoder training step on the MI355X (float32), behind ``decoder_specs.exec_train_step``.
+
+Implements /root/reference/decoder.py:185-263 + 327-345 -- forward in training mode (dropout,
+batch statistics, moving-average updates), the weighted MSE losses, back-propagation through both
+decoder stages (the encoder is frozen and runs in inference mode, decoder.py:581-582,637), the
+TensorFlow-style Adam update and the per-epoch learning-rate schedule -- as explicit kernel
+launches (include/vc_hip.h "Training step" section).  Data-parallel: one process per GPU, each with
+its own batch; the flat gradient buffer (33,186,713 floats at the shipped sizes) is all-reduced over
+RCCL before Adam; batch-norm statistics stay per replica like in the reference.
+
+All decoder variables are re-homed into ONE flat float32 arena (plus matching gradient / m / v
+arenas) so that Adam is a single launch and the all-reduce a single call; every weight-gradient
+kernel writes straight into its TF-layout slice of the gradient arena.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+import _vc
+import modules
+from modules import BN_DECAY, BN_EPS, BANK_FILTERS, gemm_launch
+
+MARGIN = 32          # zero margin (frames) around transposed operands (vc_conv_wgrad)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _lib():
+    return _vc.lib()
+
+
+def _st():
+    return _vc.current_stream()
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class _Ops:
+    """Thin wrappers over the training entry points (float32 device tensors)."""
+
+    @staticmethod
+    def transpose(X, M, Cn, ld, T, scale=None, shift=None, relu=0, pool=0, row_shift=0):
+        """-> (buffer [Cn, M + 2*MARGIN] zero-initialised, ldt).  Data starts at column MARGIN."""
+        torch = _torch()
+        ldt = M + 2 * MARGIN
+        buf = torch.zeros((Cn, ldt), dtype=torch.float32, device=X.device)
+        _vc.check(_lib().vc_transpose_pad(_p(X), M, Cn, ld, T, _p(scale), _p(shift), int(relu), int(pool),
+                                          int(row_shift), _p(buf), ldt, MARGIN, _st()))
+        return buf, ldt
+
+    @staticmethod
+    def wgrad(XT, ldxt, Cin, M, T, dYT, ldyt, groups):
+        """groups: list of (dYT_row_offset, N, taps, shift0, dW tensor/view, ldw)."""
+        d = _vc.WgradDesc()
+        d.d_XT = XT.data_ptr() + MARGIN * 4
+        d.ldxt, d.ldyt, d.Cin, d.M, d.T, d.margin, d.n_groups = ldxt, ldyt, Cin, M, T, MARGIN, len(groups)
+        for i, (roff, N, taps, shift0, dW, ldw) in enumerate(groups):
+            g = d.groups[i]
+            g.d_dYT = dYT.data_ptr() + (roff * ldyt + MARGIN) * 4
+            g.d_dW, g.N, g.taps, g.shift0, g.ldw = dW.data_ptr(), N, taps, shift0, ldw
+        _vc.check(_lib().vc_conv_wgrad(C.byref(d), _st()))
+
+    @staticmethod
+    def bn_stats(X, M, Cn, gamma, beta, mmean, mvar):
+        torch = _torch()
+        dev = X.device
+        scale, shift, mean, rstd = (torch.empty(Cn, dtype=torch.float32, device=dev) for _ in range(4))
+        ws = torch.empty(_lib().vc_stats_workspace_floats(M, Cn), dtype=torch.float32, device=dev)
+        _vc.check(_lib().vc_bn_train_stats(_p(X), M, Cn, Cn, _p(gamma), _p(beta), _p(mmean), _p(mvar),
+                                           BN_DECAY, BN_EPS, _p(scale), _p(shift), _p(mean), _p(rstd), _p(ws), _st()))
+        return scale, shift, mean, rstd
+
+    @staticmethod
+    def bn_backward(G, X, M, Cn, T, gamma, st, mode, dgamma, dbeta):
+        torch = _torch()
+        scale, shift, mean, rstd = st
+        dX = torch.empty((M, Cn), dtype=torch.float32, device=X.device)
+        ws = torch.empty(_lib().vc_stats_workspace_floats(M, Cn), dtype=torch.float32, device=X.device)
+        _vc.check(_lib().vc_bn_backward(_p(G), _p(X), M, Cn, Cn, T, _p(gamma), _p(scale), _p(shift), _p(mean), _p(rstd),
+                                        mode, _p(dX), _p(dgamma), _p(dbeta), _p(ws), _st()))
+        return dX
+
+    @staticmethod
+    def col_sum(X, M, Cn, ld, out, accumulate=0):
+        _vc.check(_lib().vc_col_sum(_p(X), M, Cn, ld, _p(out), int(accumulate), _st()))
+
+
+class DecoderTrainer:
+    """Owns the flat arenas and runs one training step for a ``decoder_specs`` object."""
+
+    def __init__(self, decoder):
+        torch = _torch()
+        self.dec = decoder
+        self.store = decoder.store
+        if self.store.dtype != torch.float32:
+            raise NotImplementedError(' - ERROR, training runs in float32 (compute_dtype must be float32)')
+        c = decoder.cfg_d
+        self.cfg = c
+        scope = decoder._scope
+        names = self.store.trainable_names(scope + '/')
+        total = sum(self.store.vars[n].numel() for n in names)
+        dev = self.store.device
+        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.names, self.offsets = names, {}
+        off = 0
+        for n in names:
+            v = self.store.vars[n]
+            k = v.numel()
+            view = self.flat[off:off + k].view(v.shape)
+            view.copy_(v)
+            self.store.vars[n] = view                      # re-home the variable into the arena
+            self.offsets[n] = (off, k, tuple(v.shape))
+            off += k
+        self.store.invalidate()
+        self.total = total
+        self.step_count = int(decoder.opt_state['dec_opt/global_step'])
+        self.seed = int(c.get('dropout_seed', 1234))
+        self.keep = 1.0 - float(c['dropout_rate'])
+        self.loss_ws = torch.empty(256, dtype=torch.float32, device=dev)
+        self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
+
+    # ---------------------------------------------------------------- helpers
+    def g(self, name):
+        """Gradient view (TF layout) of variable ``name``."""
+        off, k, shape = self.offsets[name]
+        return self.grad[off:off + k].view(shape)
+
+    def w(self, name):
+        return self.store.vars[name]
+
+    def adam_slots(self):
+        """name -> (m, v) views, for checkpointing (TF slot names <var>/Adam, <var>/Adam_1)."""
+        out = {}
+        for n, (off, k, shape) in self.offsets.items():
+            out[n] = (self.m[off:off + k].view(shape), self.v[off:off + k].view(shape))
+        return out
+
+    # ---------------------------------------------------------------- one stage forward
+    def _stage_forward(self, s, X0, cin0, E, K, n_hw, n_out, seed_base):
+        torch = _torch()
+        H = E // 2
+        N_, T_, Cp = X0.shape
+        M = N_ * T_
+        dev = X0.device
+        st = self.store
+        sv = {'X0': X0, 'cin0': cin0, 'E': E, 'K': K, 'n_hw': n_hw, 'n_out': n_out, 'M': M, 'T': T_, 'N': N_}
+        f32 = _vc.VC_F32
+        keep = self.keep if self.keep < 1.0 else 0.0
+
+        def dense(X, ldx, cin_p, scope, units, act, seed=None, out_ld=None):
+            bt, b = modules._prep_dense(st, scope, self.w(scope + '/kernel').shape[0], units)
+            ldc = units if out_ld is None else out_ld
+            out = torch.zeros((M, ldc), dtype=torch.float32, device=dev) if ldc != units else \
+                torch.empty((M, ldc), dtype=torch.float32, device=dev)
+            d = _vc.GemmDesc()
+            d.dtype, d.mode, d.d_X = f32, _vc.GEMM_PLAIN, X.data_ptr()
+            d.M, d.T, d.Cin, d.ldx, d.N, d.n_groups = M, T_, cin_p, ldx, units, 1
+            g0 = d.groups[0]
+            g0.d_Bt, g0.K, g0.taps, g0.pad_l, g0.c_off = bt.data_ptr(), cin_p, 1, 0, 0
+            d.d_epi_shift = b.data_ptr()
+            d.act = act
+            d.d_C, d.ldc, d.out_f32 = out.data_ptr(), ldc, 1
+            if seed is not None and keep > 0.0:
+                d.drop_keep, d.drop_seed = keep, seed
+            _vc.check(_lib().vc_conv_gemm(C.byref(d), _st()))
+            return out
+
+        # prenet (modules.py:274-295), dropout fused in the epilogue
+        D1 = dense(X0, Cp, Cp, s + '/prenet/dense1', E, _vc.ACT_RELU, seed_base + 1)
+        D2 = dense(D1, E, E, s + '/prenet/dense2', H, _vc.ACT_RELU, seed_base + 2)
+        sv['D1'], sv['D2'] = D1, D2
+        # conv banks: raw outputs, batch statistics (modules.py:144-166, is_training)
+        CB = BANK_FILTERS * K
+        b = s + '/CBHG/conv1d_banks'
+        groups = []
+        for k in range(1, K + 1):
+            sub = b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k))
+            groups.append((modules._prep_conv(st, sub, k, H, BANK_FILTERS), k * H, k, (k - 1) // 2, BANK_FILTERS * (k - 1)))
+        Zb = torch.empty((M, CB), dtype=torch.float32, device=dev)
+        gemm_launch(D2, M, T_, H, H, BANK_FILTERS, groups, Zb, CB, f32, out_f32=True)
+        sb = _Ops.bn_stats(Zb, M, CB, self.w(b + '/bn/gamma'), self.w(b + '/bn/beta'),
+                           self.w(b + '/bn/moving_mean'), self.w(b + '/bn/moving_variance'))
+        # conv1d_1 on pool(relu(bn(Zb))) -- normalisation, relu and pool in the operand prologue
+        p1 = s + '/CBHG/conv1d_1'
+        Q1 = torch.empty((M, H), dtype=torch.float32, device=dev)
+        gemm_launch(Zb, M, T_, CB, CB, H, [(modules._prep_conv(st, p1, 3, CB, H), 3 * CB, 3, 1, 0)], Q1, H, f32,
+                    pro_scale=sb[0], pro_shift=sb[1], pro_relu=1, pro_pool=1, out_f32=True)
+        s1 = _Ops.bn_stats(Q1, M, H, self.w(p1 + '/gamma'), self.w(p1 + '/beta'), self.w(p1 + '/moving_mean'),
+                           self.w(p1 + '/moving_variance'))
+        p2 = s + '/CBHG/conv1d_2'
+        Q2 = torch.empty((M, H), dtype=torch.float32, device=dev)
+        gemm_launch(Q1, M, T_, H, H, H, [(modules._prep_conv(st, p2, 3, H, H), 3 * H, 3, 1, 0)], Q2, H, f32,
+                    pro_scale=s1[0], pro_shift=s1[1], pro_relu=1, pro_pool=0, out_f32=True)
+        s2 = _Ops.bn_stats(Q2, M, H, self.w(p2 + '/gamma'), self.w(p2 + '/beta'), self.w(p2 + '/moving_mean'),
+                           self.w(p2 + '/moving_variance'))
+        Y = torch.empty((M, H), dtype=torch.float32, device=dev)
+        _vc.check(_lib().vc_affine_act(_p(Q2), _p(s2[0]), _p(s2[1]), 0, _p(D2), _p(Y), M * H, H, _st()))
+        sv.update(Zb=Zb, sb=sb, Q1=Q1, s1=s1, Q2=Q2, s2=s2)
+        # highways
+        Ys = [Y]
+        for i in range(n_hw):
+            bt, bias = modules._prep_highway(st, s + '/CBHG/highwaynet_{}'.format(i), H)
+            Yn = torch.empty((M, H), dtype=torch.float32, device=dev)
+            gemm_launch(Ys[-1], M, T_, H, H, bt.shape[0], [(bt, H, 1, 0, 0)], Yn, H, f32,
+                        mode=_vc.GEMM_HIGHWAY, epi_shift=bias)
+            Ys.append(Yn)
+        sv['Ys'] = Ys
+        # bidirectional GRU with saved gates
+        gs = s + '/CBHG/gru'
+        btx, bx, wh_fw, wh_bw = modules._prep_gru(st, gs, H, H)
+        xproj = torch.empty((M, 6 * H), dtype=torch.float32, device=dev)
+        gemm_launch(Ys[-1], M, T_, H, H, 6 * H, [(btx, H, 1, 0, 0)], xproj, 6 * H, f32, epi_shift=bx, out_f32=True)
+        G = torch.empty((M, 2 * H), dtype=torch.float32, device=dev)
+        gates = torch.empty((2, M, 3 * H), dtype=torch.float32, device=dev)
+        rh = torch.empty((2, M, H), dtype=torch.float32, device=dev)
+        _vc.check(_lib().vc_gru_train_forward(_p(xproj), _p(wh_fw), _p(wh_bw), N_, T_, H, _p(G), _p(gates), _p(rh), _st()))
+        sv.update(G=G, gates=gates, rh=rh, wh=(wh_fw, wh_bw), btx=btx)
+        # output projection, padded row stride so the next stage / backward get 16-byte rows
+        y = dense(G, 2 * H, 2 * H, s + '/y_logits', n_out, _vc.ACT_NONE, None, out_ld=modules._pad8(n_out))
+        sv['y'] = y
+        return y, sv
+
+    # ---------------------------------------------------------------- one stage backward
+    def _dgrad_dense(self, dY, ld, Kp, W_tf, M, T_, out=None, R=None):
+        """dX [M, Cin] = dY [M, Kp(ld)] @ W_tf[Cin, Cout]^T  (W_tf rows are the transposed operand)."""
+        torch = _torch()
+        cin, cout = W_tf.shape
+        bt = W_tf
+        if Kp != cout:
+            bt = torch.zeros((cin, Kp), dtype=torch.float32, device=W_tf.device)
+            bt[:, :cout] = W_tf
+        bt = bt.contiguous()
+        if out is None:
+            out = torch.empty((M, cin), dtype=torch.float32, device=W_tf.device)
+        gemm_launch(dY, M, T_, Kp, ld, cin, [(bt, Kp, 1, 0, 0)], out, out.shape[1], _vc.VC_F32,
+                    R=R, ldr=(R.shape[1] if R is not None else 0), out_f32=True)
+        return out
+
+    @staticmethod
+    def _dgrad_conv_weight(W_tf):
+        """[k, Cin, Cout] -> transposed operand of the data-gradient conv: [Cin, k*Cout], taps flipped."""
+        k, cin, cout = W_tf.shape
+        return W_tf.flip(0).permute(1, 0, 2).reshape(cin, k * cout).contiguous()
+
+    def _stage_backward(self, s, sv, dY, need_dx):
+        """dY: gradient w.r.t. the stage output, [M, pad8(n_out)] (padding columns zero).
+        Fills the gradient arena; returns dX0 [M, Cp] if ``need_dx``."""
+        torch = _torch()
+        f32 = _vc.VC_F32
+        M, T_, N_ = sv['M'], sv['T'], sv['N']
+        E, K, n_hw, n_out = sv['E'], sv['K'], sv['n_hw'], sv['n_out']
+        H = E // 2
+        dev = dY.device
+        ldy = dY.shape[1]
+        inv_keep = 1.0 / self.keep if self.keep < 1.0 else 1.0
+
+        # ---- output dense: y = G Wo + bo
+        o = s + '/y_logits'
+        _Ops.col_sum(dY, M, n_out, ldy, self.g(o + '/bias'))
+        GT, ldg = _Ops.transpose(sv['G'], M, 2 * H, 2 * H, T_)
+        dYT, ldyt = _Ops.transpose(dY, M, n_out, ldy, T_)
+        _Ops.wgrad(GT, ldg, 2 * H, M, T_, dYT, ldyt, [(0, n_out, 1, 0, self.g(o + '/kernel'), n_out)])
+        dG = self._dgrad_dense(dY, ldy, ldy, self.w(o + '/kernel'), M, T_)
+        del GT, dYT
+
+        # ---- GRU
+        gs = s + '/CBHG/gru'
+        wh_fw, wh_bw = sv['wh']
+        dpre = torch.empty((M, 6 * H), dtype=torch.float32, device=dev)
+        _vc.check(_lib().vc_gru_backward(_p(dG), _p(sv['G']), _p(sv['gates']), _p(wh_fw), _p(wh_bw), N_, T_, H, _p(dpre), _st()))
+        dbx = torch.empty(6 * H, dtype=torch.float32, device=dev)
+        _Ops.col_sum(dpre, M, 6 * H, 6 * H, dbx)
+        dpT, ldp = _Ops.transpose(dpre, M, 6 * H, 6 * H, T_)
+        Yn = sv['Ys'][-1]
+        YT, ldt = _Ops.transpose(Yn, M, H, H, T_)
+        grp_x = []
+        for d, dn in enumerate(('fw', 'bw')):
+            cell = '{}/bidirectional_rnn/{}/gru_cell'.format(gs, dn)
+            gk, ck = self.g(cell + '/gates/kernel'), self.g(cell + '/candidate/kernel')       # [2H,2H], [2H,H]
+            self.g(cell + '/gates/bias').copy_(dbx[d * 3 * H:d * 3 * H + 2 * H])
+            self.g(cell + '/candidate/bias').copy_(dbx[d * 3 * H + 2 * H:(d + 1) * 3 * H])
+            grp_x.append((d * 3 * H, 2 * H, 1, 0, gk[:H], 2 * H))                              # x rows of gates/kernel
+            grp_x.append((d * 3 * H + 2 * H, H, 1, 0, ck[:H], H))                              # x rows of candidate/kernel
+        _Ops.wgrad(YT, ldt, H, M, T_, dpT, ldp, grp_x)
+        for d, dn in enumerate(('fw', 'bw')):
+            cell = '{}/bidirectional_rnn/{}/gru_cell'.format(gs, dn)
+            gk, ck = self.g(cell + '/gates/kernel'), self.g(cell + '/candidate/kernel')
+            Gd = sv['G'][:, d * H:(d + 1) * H]                                                  # view, ld = 2H
+            HpT, ldh = _Ops.transpose(Gd, M, H, 2 * H, T_, row_shift=(-1 if d == 0 else 1))   # h_{prev}
+            _Ops.wgrad(HpT, ldh, H, M, T_, dpT, ldp, [(d * 3 * H, 2 * H, 1, 0, gk[H:], 2 * H)])
+            RT, ldr = _Ops.transpose(sv['rh'][d], M, H, H, T_)
+            _Ops.wgrad(RT, ldr, H, M, T_, dpT, ldp, [(d * 3 * H + 2 * H, H, 1, 0, ck[H:], H)])
+        # input gradient: dYn = dpre @ Btx  (Btx [6H, H] -> transposed operand [H, 6H])
+        dYc = self._dgrad_dense(dpre, 6 * H, 6 * H, sv['btx'].t().contiguous(), M, T_)
+        del dpT, YT, dpre
+
+        # ---- highways (reverse)
+        for i in range(n_hw - 1, -1, -1):
+            hs = s + '/CBHG/highwaynet_{}'.format(i)
+            bt, bias = modules._prep_highway(self.store, hs, H)
+            NP = bt.shape[0]
+            Xi = sv['Ys'][i]
+            pre = torch.empty((M, NP), dtype=torch.float32, device=dev)
+            gemm_launch(Xi, M, T_, H, H, NP, [(bt, H, 1, 0, 0)], pre, NP, f32, epi_shift=bias, out_f32=True)
+            dp = torch.empty((M, NP), dtype=torch.float32, device=dev)
+            dXd = torch.empty((M, H), dtype=torch.float32, device=dev)
+            _vc.check(_lib().vc_highway_backward(_p(pre), NP, _p(Xi), _p(dYc), M, H, _p(dp), _p(dXd), _st()))
+            XT, ldx = _Ops.transpose(Xi, M, H, H, T_)
+            dpT, ldp = _Ops.transpose(dp, M, NP, NP, T_)
+            dbp = torch.empty(NP, dtype=torch.float32, device=dev)
+            _Ops.col_sum(dp, M, NP, NP, dbp)
+            g1, g2 = self.g(hs + '/dense1/kernel'), self.g(hs + '/dense2/kernel')
+            b1, b2 = self.g(hs + '/dense1/bias'), self.g(hs + '/dense2/bias')
+            grp = []
+            for q in range((H + 31) // 32):
+                n = min(32, H - 32 * q)
+                grp.append((64 * q, n, 1, 0, g1[:, 32 * q:], H))
+                grp.append((64 * q + 32, n, 1, 0, g2[:, 32 * q:], H))
+                b1[32 * q:32 * q + n].copy_(dbp[64 * q:64 * q + n])
+                b2[32 * q:32 * q + n].copy_(dbp[64 * q + 32:64 * q + 32 + n])
+            for j in range(0, len(grp), 32):
+                _Ops.wgrad(XT, ldx, H, M, T_, dpT, ldp, grp[j:j + 32])
+            # dX = dp @ bt (paired) + direct path
+            dYc = self._dgrad_dense(dp, NP, NP, bt.t().contiguous(), M, T_, R=dXd)
+            del pre, dp, XT, dpT
+
+        # ---- Y0 = bn2(Q2) + D2
+        p2 = s + '/CBHG/conv1d_2'
+        dQ2 = _Ops.bn_backward(dYc, sv['Q2'], M, H, T_, self.w(p2 + '/gamma'), sv['s2'], 0,
+                               self.g(p2 + '/gamma'), self.g(p2 + '/beta'))
+        dD2_res = dYc
+        # conv1d_2 on relu(bn1(Q1))
+        W2c = self.w(p2 + '/conv1d/kernel')
+        R1T, ldr1 = _Ops.transpose(sv['Q1'], M, H, H, T_, scale=sv['s1'][0], shift=sv['s1'][1], relu=1)
+        dQ2T, ldq2 = _Ops.transpose(dQ2, M, H, H, T_)
+        _Ops.wgrad(R1T, ldr1, H, M, T_, dQ2T, ldq2, [(0, H, 3, -1, self.g(p2 + '/conv1d/kernel'), H)])
+        dR1 = torch.empty((M, H), dtype=torch.float32, device=dev)
+        gemm_launch(dQ2, M, T_, H, H, H, [(self._dgrad_conv_weight(W2c), 3 * H, 3, 1, 0)], dR1, H, f32, out_f32=True)
+        del R1T, dQ2T
+        p1 = s + '/CBHG/conv1d_1'
+        dQ1 = _Ops.bn_backward(dR1, sv['Q1'], M, H, T_, self.w(p1 + '/gamma'), sv['s1'], 1,
+                               self.g(p1 + '/gamma'), self.g(p1 + '/beta'))
+        # conv1d_1 on pool(relu(bnb(Zb)))
+        CB = BANK_FILTERS * K
+        W1c = self.w(p1 + '/conv1d/kernel')
+        PT, ldpt = _Ops.transpose(sv['Zb'], M, CB, CB, T_, scale=sv['sb'][0], shift=sv['sb'][1], relu=1, pool=1)
+        dQ1T, ldq1 = _Ops.transpose(dQ1, M, H, H, T_)
+        _Ops.wgrad(PT, ldpt, CB, M, T_, dQ1T, ldq1, [(0, H, 3, -1, self.g(p1 + '/conv1d/kernel'), H)])
+        del PT, dQ1T
+        dP = torch.empty((M, CB), dtype=torch.float32, device=dev)
+        gemm_launch(dQ1, M, T_, H, H, CB, [(self._dgrad_conv_weight(W1c), 3 * H, 3, 1, 0)], dP, CB, f32, out_f32=True)
+        b = s + '/CBHG/conv1d_banks'
+        dZb = _Ops.bn_backward(dP, sv['Zb'], M, CB, T_, self.w(b + '/bn/gamma'), sv['sb'], 2,
+                               self.g(b + '/bn/gamma'), self.g(b + '/bn/beta'))
+        del dP
+        # banks: filter gradients (one grouped launch) and data gradient accumulated bank by bank
+        D2T, ldd2 = _Ops.transpose(sv['D2'], M, H, H, T_)
+        dZbT, ldzb = _Ops.transpose(dZb, M, CB, CB, T_)
+        grp = []
+        for k in range(1, K + 1):
+            sub = b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k))
+            grp.append((BANK_FILTERS * (k - 1), BANK_FILTERS, k, -((k - 1) // 2), self.g(sub + '/conv1d/kernel'), BANK_FILTERS))
+        _Ops.wgrad(D2T, ldd2, H, M, T_, dZbT, ldzb, grp)
+        del D2T, dZbT
+        dD2 = dD2_res.clone()
+        for k in range(1, K + 1):
+            sub = b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k))
+            Wk = self.w(sub + '/conv1d/kernel')                                      # [k, H, 128]
+            Xk = dZb[:, BANK_FILTERS * (k - 1):]                                     # view: ld = CB, Cin = 128
+            gemm_launch(Xk, M, T_, BANK_FILTERS, CB, H, [(self._dgrad_conv_weight(Wk), k * BANK_FILTERS, k, k - 1 - (k - 1) // 2, 0)],
+                        dD2, H, f32, R=dD2, ldr=H, out_f32=True)
+        del dZb
+
+        # ---- prenet
+        pn = s + '/prenet'
+        D1, D2, X0 = sv['D1'], sv['D2'], sv['X0']
+        Cp = X0.shape[2]
+        cin0 = sv['cin0']
+        dZ2 = torch.empty((M, H), dtype=torch.float32, device=dev)
+        _vc.check(_lib().vc_relu_dropout_backward(_p(dD2), _p(D2), inv_keep, _p(dZ2), M * H, _st()))
+        _Ops.col_sum(dZ2, M, H, H, self.g(pn + '/dense2/bias'))
+        D1T, ld1 = _Ops.transpose(D1, M, E, E, T_)
+        dZ2T, ldz2 = _Ops.transpose(dZ2, M, H, H, T_)
+        _Ops.wgrad(D1T, ld1, E, M, T_, dZ2T, ldz2, [(0, H, 1, 0, self.g(pn + '/dense2/kernel'), H)])
+        dD1 = self._dgrad_dense(dZ2, H, H, self.w(pn + '/dense2/kernel'), M, T_)
+        del D1T, dZ2T
+        dZ1 = torch.empty((M, E), dtype=torch.float32, device=dev)
+        _vc.check(_lib().vc_relu_dropout_backward(_p(dD1), _p(D1), inv_keep, _p(dZ1), M * E, _st()))
+        _Ops.col_sum(dZ1, M, E, E, self.g(pn + '/dense1/bias'))
+        X0v = X0.view(M, Cp)
+        X0T, ldx0 = _Ops.transpose(X0v, M, cin0, Cp, T_)
+        dZ1T, ldz1 = _Ops.transpose(dZ1, M, E, E, T_)
+        _Ops.wgrad(X0T, ldx0, cin0, M, T_, dZ1T, ldz1, [(0, E, 1, 0, self.g(pn + '/dense1/kernel'), E)])
+        dX0 = None
+        if need_dx:
+            W1 = self.w(pn + '/dense1/kernel')                                       # [cin0, E]
+            W1p = torch.zeros((Cp, E), dtype=torch.float32, device=dev)
+            W1p[:cin0] = W1
+            dX0 = self._dgrad_dense(dZ1, E, E, W1p, M, T_)
+        return dX0
+
+    # ---------------------------------------------------------------- whole step
+    def forward_backward(self, x, target_mel, target_stft):
+        """Forward + backward of one batch.  Returns the device tensor [mel_loss, stft_loss]."""
+        torch = _torch()
+        dec, c = self.dec, self.cfg
+        if c['loss_type'] not in ('sum', 'log'):
+            raise Exception('- ERROR, _build_loss, loss_type not understood.')
+        n_in = c['input_shape'][-1]
+        pad = modules._pad8(n_in)
+        if dec.encoder is not None:
+            ppg = dec.encoder.forward(x, ppg_pad_to=pad, ppg_dtype=torch.float32)['ppg']
+        else:
+            ppg = torch.zeros((x.shape[0], x.shape[1], pad), dtype=torch.float32, device=x.device)
+            ppg[:, :, :n_in] = x
+        self.last_ppg = ppg
+        M = ppg.shape[0] * ppg.shape[1]
+        sd1, sd2 = c['steps_v'][0], c['steps_v'][1]
+        seed = self.seed + 1000 * self.step_count
+        with modules.variable_store(self.store):
+            s1, s2 = dec._scope + '/step1', dec._scope + '/step2'
+            y1, sv1 = self._stage_forward(s1, ppg, n_in, dec._E[0], sd1['num_conv_banks'], sd1['num_highwaynet_blocks'],
+                                          sd1['n_output'], seed)
+            n1 = sd1['n_output']
+            x2 = y1.view(ppg.shape[0], ppg.shape[1], y1.shape[1])
+            y2, sv2 = self._stage_forward(s2, x2, n1, dec._E[1], sd2['num_conv_banks'], sd2['num_highwaynet_blocks'],
+                                          sd2['n_output'], seed + 10)
+            n2 = sd2['n_output']
+            self.y_mel = y1[:, :n1].contiguous() if y1.shape[1] != n1 else y1
+            self.y_stft = y2[:, :n2].contiguous() if y2.shape[1] != n2 else y2
+            # losses + output gradients (decoder.py:187-195)
+            dY1 = torch.zeros_like(y1)
+            dY2 = torch.zeros_like(y2)
+            wm, ws = float(c['mel_loss_weight']), float(c['stft_loss_weight'])
+            _vc.check(_lib().vc_mse_loss(_p(self.y_mel), _p(target_mel), M * n1, wm, _p(dY1), n1, y1.shape[1],
+                                         _p(self.losses[0:1]), _p(self.loss_ws), _st()))
+            _vc.check(_lib().vc_mse_loss(_p(self.y_stft), _p(target_stft), M * n2, ws, _p(dY2), n2, y2.shape[1],
+                                         _p(self.losses[1:2]), _p(self.loss_ws), _st()))
+            if c['loss_type'] == 'log':          # d log(L) = dL / L  (host round trip for the two scalars)
+                lm, ls = (float(v) for v in self.losses.cpu())
+                dY1.mul_(1.0 / lm)
+                dY2.mul_(1.0 / ls)
+            dX2 = self._stage_backward(s2, sv2, dY2, need_dx=True)
+            del sv2
+            dY1.add_(dX2)                         # y_mel feeds step 2 (decoder.py:155)
+            self._stage_backward(s1, sv1, dY1, need_dx=False)
+        return self.losses
+
+    def apply_gradients(self, world=1):
+        """All-reduce (data parallel), Adam, bookkeeping.  decoder.py:236-246."""
+        torch = _torch()
+        c = self.cfg
+        if world > 1:
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+        self.step_count += 1
+        t = self.step_count
+        lr = float(self.dec.opt_state['dec_opt/learning_rate'])
+        b1, b2, eps = float(c['beta1']), float(c['beta2']), float(c['epsilon'])
+        lr_t = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+        _vc.check(_lib().vc_adam_step(_p(self.flat), _p(self.grad), _p(self.m), _p(self.v), self.total, lr_t, b1, b2, eps,
+                                      1.0 / world, _st()))
+        self.store.invalidate()                   # kernel-layout copies are stale now
+        self.dec.opt_state['dec_opt/global_step'] = np.int32(t)
+        return t
