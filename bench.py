@@ -220,6 +220,49 @@ def bench_full(args, rank, world):
     return frames, dt, extra, cfg
 
 
+def bench_train(args, rank, world):
+    """BASELINE configs[4]: decoder training step (fwd + bwd + Adam, float32) on synthetic
+    ARCTIC-slt-shaped targets, 32 windows per GPU, gradients all-reduced over RCCL."""
+    import contextlib
+    import io
+    B, T = 32, 400
+    enc, dec = None, None
+    with contextlib.redirect_stdout(io.StringIO()):
+        from aux_func import load_cfg_d
+        from encoder import encoder_spec_phn
+        from decoder import decoder_specs
+        hp = os.path.join(ROOT, 'speech-cloner_amd', 'hp')
+        enc_cfg = load_cfg_d(os.path.join(hp, 'encoder_cfg_d.json'))
+        dec_cfg = load_cfg_d(os.path.join(hp, 'decoder_cfg_d.json'))
+        enc_cfg.update(is_training=False, model_path=os.path.join(ROOT, 'tests', 'golden', 'enc_14_ckpt'))
+        dec_cfg.update(is_training=True)
+        enc = encoder_spec_phn(enc_cfg, None)
+        dec = decoder_specs(dec_cfg, None, enc)
+    g = torch.Generator().manual_seed(100 + rank)
+    mfcc = (torch.rand(B, T, 80, generator=g) * 0.4 - 0.2).cuda()
+    mel = (torch.rand(B, T, 80, generator=g) * 0.8).cuda()
+    stft = (torch.rand(B, T, 201, generator=g) * 0.8).cuda()
+    last = None
+    for _ in range(args.warmup):
+        last = dec.exec_train_step(mfcc, mel, stft)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        last = dec.exec_train_step(mfcc, mel, stft)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    extra = {'stages': {'last_loss': float(last[2]), 'global_step': int(last[3]),
+                        'params': int(dec._trainer.total), 'allreduce_MB': round(dec._trainer.total * 4 / 1e6, 1)}}
+    cfg = {'workload': 'train: decoder fwd+bwd+Adam (float32) on 32 windows x 400 frames per GPU, encoder frozen '
+                       '(BASELINE configs[4])', 'global_batch': B * world, 'frames_per_step_per_gpu': B * T}
+    return B * T, dt, extra, cfg
+
+
 def cpu_baseline_full():
     """Oracle timed on the host: front-end on 2 utterances (numpy) + encode/decode of 2 windows with
     torch-CPU float32 ops at the shipped sizes (all host threads)."""
@@ -277,7 +320,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='full', choices=['full', 'frontend'])
+    ap.add_argument('--workload', default='full', choices=['full', 'frontend', 'train'])
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
     ap.add_argument('--window-batch', type=int, default=64)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -292,6 +335,9 @@ def main():
 
     if args.workload == 'frontend':
         frames, dt, extra, cfg = bench_frontend(args, rank, world)
+    elif args.workload == 'train':
+        frames, dt, extra, cfg = bench_train(args, rank, world)
+        args.no_cpu_baseline = True
     else:
         frames, dt, extra, cfg = bench_full(args, rank, world)
 
@@ -300,7 +346,7 @@ def main():
         line = {'metric': 'mel frames/sec', 'value': round(frames * world * args.steps / dt, 1), 'unit': 'frames/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(dt / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak',
-                'vs_baseline': None, 'dtype': 'f32' if args.workload == 'frontend' else
+                'vs_baseline': None, 'dtype': 'f32' if args.workload in ('frontend', 'train') else
                 ('bf16' if args.dtype == 'bfloat16' else 'f32'), 'data': 'synthetic',
                 'config': dict(cfg, parallelism='utterance-sharded x%d, no collective' % world)}
         line.update(extra)

@@ -133,3 +133,66 @@ def test_train_checkpoint_has_adam_slots(tmp_path):
     assert int(ck['dec_opt/global_step']) == 1
     k = 'decoder/step1/prenet/dense1/kernel'
     assert ck['dec_opt/' + k + '/Adam'].shape == ck[k].shape and np.abs(ck['dec_opt/' + k + '/Adam_1']).max() > 0
+
+
+_DP_WORKER = r'''
+import os, sys, json
+import numpy as np, torch
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, 'speech-cloner_amd')); sys.path.insert(0, os.path.join(root, 'tests'))
+import dist_util
+from test_training_gpu import _cfg, _setup
+rank, world = dist_util.init('gloo')           # 2 ranks share the one GPU of the test box -> gloo moves the CUDA buffers
+torch.cuda.set_device(0)
+cfg = _cfg()
+dec, w, _, _, _ = _setup(cfg)
+rng = np.random.RandomState(100 + rank)
+def batch(r):
+    g = np.random.RandomState(100 + r)
+    ppg = torch.softmax(torch.from_numpy(g.standard_normal((4, 40, 61)) * 2), -1).float().numpy()
+    return ppg, g.uniform(0, 0.8, (4, 40, 80)).astype(np.float32), g.uniform(0, 0.8, (4, 40, 201)).astype(np.float32)
+tr = dec._get_trainer()
+mine = batch(rank)
+tr.forward_backward(*(torch.from_numpy(a).cuda() for a in mine))
+g_local = tr.grad.clone()
+p_before = tr.flat.clone()
+tr.apply_gradients(world)                       # all-reduce + Adam with grad_scale 1/world
+# reference on every rank: the other rank's gradient computed locally with identical weights/seeds
+dec2, _, _, _, _ = _setup(_cfg())
+tr2 = dec2._get_trainer()
+other = batch(1 - rank)
+tr2.forward_backward(*(torch.from_numpy(a).cuda() for a in other))
+total = g_local + tr2.grad
+err = float((tr.grad - total).abs().max() / total.abs().max())
+# Adam step from the averaged gradient
+m = 0.1 * (total / world); v = 0.001 * (total / world) ** 2
+lr_t = 1e-3 * (1 - 0.999) ** 0.5 / (1 - 0.9)
+p_ref = p_before - lr_t * m / (v.sqrt() + 1e-8)
+perr = float((tr.flat - p_ref).abs().max())
+flat = dist_util.gather_concat(tr.flat[:1000].cpu().numpy().reshape(1, -1))
+same = bool(np.array_equal(flat[0], flat[1]))   # replicas stay bit-identical after the update
+if rank == 0:
+    print('DP_RESULT', json.dumps({'grad_err': err, 'param_err': perr, 'replicas_equal': same}))
+dist_util.finalize()
+'''
+
+
+def test_data_parallel_two_ranks(tmp_path):
+    """BASELINE config 5 shape of the exchange: each rank trains on its own batch, gradients are
+    summed over ranks (all-reduce of the flat arena) and scaled by 1/world inside Adam; batch-norm
+    statistics stay per replica.  Two processes share this box's single GPU, so the process group
+    uses gloo here (the multi-GPU bench uses nccl = RCCL)."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / 'dp.py'
+    script.write_text(_DP_WORKER)
+    port = 29600 + (os.getpid() % 300)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), str(script), ROOT]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420)
+    line = [l for l in r.stdout.splitlines() if l.startswith('DP_RESULT')]
+    assert r.returncode == 0 and line, r.stdout[-3000:] + r.stderr[-3000:]
+    res = json.loads(line[0].split(' ', 1)[1])
+    assert res['grad_err'] < 1e-6 and res['param_err'] < 1e-6 and res['replicas_equal'], res
