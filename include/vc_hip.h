@@ -269,8 +269,9 @@ int vc_relu_dropout_backward(const float* d_dY, const float* d_Y, float inv_keep
  * forward's paired column layout [M, NP]; writes d(pre) [M, NP] and the direct path dO*(1-T). */
 int vc_highway_backward(const float* d_pre, int32_t NP, const float* d_X, const float* d_dO, int32_t M, int32_t H,
                         float* d_dpre, float* d_dXd, void* stream);
-/* out[c] (+)= sum_m X[m, c]  (bias gradients). */
-int vc_col_sum(const float* d_X, int32_t M, int32_t C, int32_t ld, float* d_out, int32_t accumulate, void* stream);
+/* out[c] (+)= sum_m X[m, c]  (bias gradients); d_workspace: 64 * C floats. */
+int vc_col_sum(const float* d_X, int32_t M, int32_t C, int32_t ld, float* d_out, int32_t accumulate,
+               float* d_workspace, void* stream);
 int vc_fill(float* d_p, float value, size_t n, void* stream);
 /* loss = weight * mean((y - t)^2) (decoder.py:187-189); optional d_dY = 2*weight/n * (y - t).
  * y/t are contiguous [n/C, C]; d_dY is written with row stride ld_dy >= C (padding columns are

@@ -10,6 +10,7 @@
 // step -- that costs >= 1 us on this chip (MI355X_MICROARCH.md, hand-off price list), more than a
 // whole step.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "vc_common.h"
 
@@ -20,6 +21,10 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float ld_w(const float* p) { return *p; }
 __device__ __forceinline__ float ld_w(const __bf16* p) { return (float)*p; }
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// bf16 recurrences: v_exp_f32 + v_rcp_f32 (1 ulp each) instead of libm tanhf / IEEE division --
+// the gate arithmetic of 16 sequences lands on one CU in the MFMA kernel, so it must be cheap.
+__device__ __forceinline__ float fast_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ float fast_tanh(float v) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * v) + 1.0f); }
 
 struct GruArgs {
     const float* xproj;     // [n_seq*T, 6H]
@@ -291,6 +296,203 @@ int launch_resident(const GruArgs& a, void* ws, size_t ws_bytes, hipStream_t st)
 
 
 // ------------------------------------------------------------------------------------------
+// MFMA recurrence (bf16, H = 128 / 256): ONE workgroup advances 16 sequences of one direction.
+//   v_mfma_f32_16x16x32_bf16:  D[unit i][seq n] += A[unit i][k] * B[k][seq n]
+//   A = transposed recurrent weights (tile of 16 hidden units x 32 k), resident for all T steps:
+//       gate (r,u) tiles in VGPRs, candidate tiles in VGPRs (H = 128) or LDS (H = 256: 128 KB);
+//   B = the 16 hidden-state vectors (bf16, LDS, one ds_read_b128 per lane and k-step).
+// Wave w owns hidden units [w*H/8, (w+1)*H/8): its r, u and c accumulators for a (unit, sequence)
+// pair live in the same lane and register, so the whole gate arithmetic is lane-local; only r*h
+// and h cross waves (LDS, two barriers per step).  The matrix work of a step costs 3H^2*16 MAC
+// at 2048 MAC/clk/CU = 0.64 us (H = 256), independent of how many of the 16 slots are used.
+typedef float f32x4m __attribute__((ext_vector_type(4)));
+
+template <int H> struct MfGeom {
+    static constexpr int NW = 8, UW = H / NW, TPW = UW / 16, KSN = H / 32;
+    static constexpr int NF_G = 2 * TPW * KSN, NF_C = TPW * KSN, NF = NF_G + NF_C;   // fragments per wave
+    static constexpr int PITCH = H + 8;                       // bf16 elements per LDS row of h
+    static constexpr bool CAND_LDS = (H >= 256);
+};
+
+// packed[dir][wave][frag][lane][8]: frag f < NF_G: gate g = f / (TPW*KSN) (0 = r, 1 = u), else candidate
+template <int H>
+__global__ void __launch_bounds__(256)
+gru_mfma_pack_kernel(const __bf16* W0, const __bf16* W1, __bf16* packed) {
+    typedef MfGeom<H> G;
+    const int total = 2 * G::NW * G::NF * 64 * 8;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        int r = idx;
+        const int j = r & 7; r >>= 3;
+        const int lane = r & 63; r >>= 6;
+        const int f = r % G::NF; r /= G::NF;
+        const int wave = r % G::NW;
+        const int dir = r / G::NW;
+        int g, rem;
+        if (f < G::NF_G) { g = f / (G::TPW * G::KSN); rem = f % (G::TPW * G::KSN); }
+        else { g = 2; rem = f - G::NF_G; }
+        const int tl = rem / G::KSN, ks = rem % G::KSN;
+        const int k = ks * 32 + 8 * (lane >> 4) + j;
+        const int col = g * H + wave * G::UW + tl * 16 + (lane & 15);
+        const __bf16* W = dir ? W1 : W0;
+        packed[idx] = W[(size_t)k * 3 * H + col];
+    }
+}
+
+template <int H>
+__global__ void __launch_bounds__(512, 2)
+gru_mfma_kernel(GruArgs a, const __bf16* packed) {
+    typedef MfGeom<H> G;
+    constexpr int TPW = G::TPW, KSN = G::KSN, PITCH = G::PITCH, UW = G::UW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* hb = reinterpret_cast<__bf16*>(smem);                 // [16][PITCH]
+    __bf16* rhb = hb + 16 * PITCH;                                // [16][PITCH]
+    bf16x8v* candL = reinterpret_cast<bf16x8v*>(rhb + 16 * PITCH);   // [NW][NF_C][64] when CAND_LDS
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int dir = blockIdx.y, seq0 = blockIdx.x * 16;
+    const int n = lane & 15, q = lane >> 4;
+    const int seq = min(seq0 + n, a.n_seq - 1);
+    const bool seq_ok = (seq0 + n) < a.n_seq;
+    const bf16x8v* pk = reinterpret_cast<const bf16x8v*>(packed) + ((size_t)(dir * G::NW + wave) * G::NF) * 64 + lane;
+
+    bf16x8v wg[G::NF_G];
+#pragma unroll
+    for (int f = 0; f < G::NF_G; ++f) wg[f] = pk[(size_t)f * 64];
+    bf16x8v wc[G::CAND_LDS ? 1 : G::NF_C];
+    if (G::CAND_LDS) {
+#pragma unroll
+        for (int f = 0; f < G::NF_C; ++f) candL[(wave * G::NF_C + f) * 64 + lane] = pk[(size_t)(G::NF_G + f) * 64];
+    } else {
+#pragma unroll
+        for (int f = 0; f < G::NF_C; ++f) wc[f] = pk[(size_t)(G::NF_G + f) * 64];
+    }
+    for (int i = tid; i < 2 * 16 * PITCH; i += 512) hb[i] = (__bf16)0.0f;       // hb and rhb are adjacent
+    float hreg[TPW][4];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hreg[tl][e] = 0.0f;
+
+    const int H3 = 3 * H;
+    const size_t xrow = 6 * (size_t)H;
+    const int ucol = wave * UW + q * 4;                          // first of this lane's 4 units in tile 0
+    const float* xbase = a.xproj + (size_t)seq * a.T * xrow + (size_t)dir * H3 + ucol;
+    int t = dir ? a.T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    f32x4m xr[TPW], xu[TPW], xc[TPW];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) {
+        const float* xp = xbase + (size_t)t * xrow + tl * 16;
+        xr[tl] = *reinterpret_cast<const f32x4m*>(xp);
+        xu[tl] = *reinterpret_cast<const f32x4m*>(xp + H);
+        xc[tl] = *reinterpret_cast<const f32x4m*>(xp + 2 * H);
+    }
+    __syncthreads();
+
+    const __bf16* hrow = hb + n * PITCH + 8 * q;                 // B-fragment source of this lane
+    const __bf16* rrow = rhb + n * PITCH + 8 * q;
+    for (int step = 0; step < a.T; ++step, t += dt) {
+        const bool more = step + 1 < a.T;
+        const float* xn = xbase + (size_t)(more ? t + dt : t) * xrow;
+        // ---- phase 1: r and u pre-activations.  All h fragments are fetched up front so the MFMA
+        // chain never waits on an LDS read it has just issued.
+        bf16x8v bfr[KSN];
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8v*>(hrow + ks * 32);
+        f32x4m ar[TPW], au[TPW];
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+            ar[tl] = xr[tl];
+            au[tl] = xu[tl];
+            xr[tl] = *reinterpret_cast<const f32x4m*>(xn + tl * 16);          // next step's, in place
+            xu[tl] = *reinterpret_cast<const f32x4m*>(xn + tl * 16 + H);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) {
+#pragma unroll
+            for (int tl = 0; tl < TPW; ++tl) {
+                ar[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[(0 * TPW + tl) * KSN + ks], bfr[ks], ar[tl], 0, 0, 0);
+                au[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[(1 * TPW + tl) * KSN + ks], bfr[ks], au[tl], 0, 0, 0);
+            }
+        }
+        float uu[TPW][4];
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+            typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+            bf16x4v o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float r = fast_sigmoid(ar[tl][e]);
+                uu[tl][e] = fast_sigmoid(au[tl][e]);
+                o[e] = (__bf16)(r * hreg[tl][e]);
+            }
+            *reinterpret_cast<bf16x4v*>(rhb + n * PITCH + ucol + tl * 16) = o;
+        }
+        __syncthreads();
+        // ---- phase 2: candidate, state update
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8v*>(rrow + ks * 32);
+        f32x4m ac[TPW];
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+            ac[tl] = xc[tl];
+            xc[tl] = *reinterpret_cast<const f32x4m*>(xn + tl * 16 + 2 * H);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) {
+#pragma unroll
+            for (int tl = 0; tl < TPW; ++tl) {
+                const bf16x8v w = G::CAND_LDS ? candL[(wave * G::NF_C + tl * KSN + ks) * 64 + lane] : wc[G::CAND_LDS ? 0 : tl * KSN + ks];
+                ac[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bfr[ks], ac[tl], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+            typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+            bf16x4v o;
+            f32x4m hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = fast_tanh(ac[tl][e]);
+                const float hn = uu[tl][e] * hreg[tl][e] + (1.0f - uu[tl][e]) * c;
+                hreg[tl][e] = hn;
+                hv[e] = hn;
+                o[e] = (__bf16)hn;
+            }
+            *reinterpret_cast<bf16x4v*>(hb + n * PITCH + ucol + tl * 16) = o;
+            if (seq_ok) {
+                const size_t oi = ((size_t)seq * a.T + t) * 2 * H + (size_t)dir * H + ucol + tl * 16;
+                if (a.out_bf16) *reinterpret_cast<bf16x4v*>(reinterpret_cast<__bf16*>(a.out) + oi) = o;
+                else *reinterpret_cast<f32x4m*>(reinterpret_cast<float*>(a.out) + oi) = hv;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int H>
+int launch_mfma(const GruArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    typedef MfGeom<H> G;
+    const size_t need = 2 * (size_t)3 * H * H * sizeof(__bf16);
+    if (ws == nullptr || ws_bytes < need)
+        return vc::set_error(VC_ERR_WORKSPACE, "vc_gru_bidir: workspace too small (%zu < %zu)", ws_bytes, need);
+    __bf16* packed = static_cast<__bf16*>(ws);
+    hipLaunchKernelGGL((gru_mfma_pack_kernel<H>), dim3(256), dim3(256), 0, st, static_cast<const __bf16*>(a.Wh[0]),
+                       static_cast<const __bf16*>(a.Wh[1]), packed);
+    const size_t lds = 2 * 16 * (size_t)G::PITCH * 2 + (G::CAND_LDS ? (size_t)G::NW * G::NF_C * 64 * 16 : 0);
+    static bool attr_done = false;
+    if (!attr_done) {
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma_kernel<H>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gru_mfma_kernel<H>), dim3((a.n_seq + 15) / 16, 2), dim3(512), lds, st, a,
+                       static_cast<const __bf16*>(packed));
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Single-wave recurrence for small H (the encoder: H = 40): one 64-lane wave per (window,
 // direction), no LDS and no barriers.  Lane j owns hidden unit j: its three weight columns
 // (r_j, u_j, c_j: 3H f32 registers) and h_j.  h is broadcast to the wave one element at a time
@@ -417,8 +619,14 @@ int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw,
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(n_seq, 2);
     // register-resident kernels for the decoder's sizes
-    if (w_dtype == VC_BF16 && H == 256) return launch_resident<256, __bf16, 512>(a, d_workspace, workspace_bytes, st);
-    if (w_dtype == VC_BF16 && H == 128) return launch_resident<128, __bf16, 1024>(a, d_workspace, workspace_bytes, st);
+    // bf16: one sequence per workgroup, weights in VGPRs (default, 1.8 us/step at H = 256).
+    // VC_GRU_MFMA=1 selects the 16-sequences-per-workgroup MFMA kernel instead: it needs 16x fewer
+    // CUs but measured 3.3 us/step in round 1, so it stays opt-in until it is faster.
+    static const bool use_valu = (getenv("VC_GRU_MFMA") == nullptr);
+    if (w_dtype == VC_BF16 && H == 256) return use_valu ? launch_resident<256, __bf16, 512>(a, d_workspace, workspace_bytes, st)
+                                                        : launch_mfma<256>(a, d_workspace, workspace_bytes, st);
+    if (w_dtype == VC_BF16 && H == 128) return use_valu ? launch_resident<128, __bf16, 1024>(a, d_workspace, workspace_bytes, st)
+                                                        : launch_mfma<128>(a, d_workspace, workspace_bytes, st);
     if (w_dtype == VC_F32 && H == 128) return launch_resident<128, float, 1024>(a, d_workspace, workspace_bytes, st);
     if (H == 40) {                                      // the shipped encoder (hp/encoder_cfg_d.json)
         if (w_dtype == VC_F32) hipLaunchKernelGGL((gru_wave_kernel<40, float>), grid, dim3(64), 0, st, a);

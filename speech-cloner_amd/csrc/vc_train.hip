@@ -234,13 +234,27 @@ transpose_pad_kernel(const float* X, int M, int C, int ld, int T, const float* s
     }
 }
 
-// column sums (bias gradients): out[c] (+)= sum_m X[m][c]
+// column sums (bias gradients): out[c] (+)= sum_m X[m][c].  One block = 64 columns x 4 row
+// groups; rows are strided over blockIdx.y * 4 + group, partials combined in a fixed order
+// (deterministic) by the last kernel.
 __global__ void __launch_bounds__(TB)
-col_sum_kernel(const float* X, int M, int C, int ld, float* out, int accumulate) {
+col_sum_partial_kernel(const float* X, int M, int C, int ld, int nrb, float* part) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.0f;
+    if (c < C)
+        for (int r = blockIdx.y * 4 + rg; r < M; r += nrb * 4) s += X[(size_t)r * ld + c];
+    red[rg][cl] = s;
+    __syncthreads();
+    if (rg == 0 && c < C) part[(size_t)blockIdx.y * C + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+__global__ void __launch_bounds__(TB)
+col_sum_final_kernel(const float* part, int nrb, int C, float* out, int accumulate) {
     const int c = blockIdx.x * TB + threadIdx.x;
     if (c >= C) return;
     double s = 0.0;
-    for (int r = 0; r < M; ++r) s += (double)X[(size_t)r * ld + c];
+    for (int b = 0; b < nrb; ++b) s += (double)part[(size_t)b * C + c];
     out[c] = (accumulate ? out[c] : 0.0f) + (float)s;
 }
 
@@ -506,10 +520,13 @@ int vc_transpose_pad(const float* d_X, int32_t M, int32_t C, int32_t ld, int32_t
     return VC_OK;
 }
 
-int vc_col_sum(const float* d_X, int32_t M, int32_t C, int32_t ld, float* d_out, int32_t accumulate, void* stream) {
-    VC_REQUIRE(d_X && d_out && M > 0 && C > 0 && ld >= C, "bad argument");
-    hipLaunchKernelGGL(col_sum_kernel, dim3((C + TB - 1) / TB), dim3(TB), 0, static_cast<hipStream_t>(stream), d_X, M, C, ld,
-                       d_out, accumulate);
+int vc_col_sum(const float* d_X, int32_t M, int32_t C, int32_t ld, float* d_out, int32_t accumulate,
+               float* d_workspace, void* stream) {
+    VC_REQUIRE(d_X && d_out && d_workspace && M > 0 && C > 0 && ld >= C, "bad argument");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nrb = 64;                                   // workspace: 64 * C floats
+    hipLaunchKernelGGL(col_sum_partial_kernel, dim3((C + 63) / 64, nrb), dim3(TB), 0, st, d_X, M, C, ld, nrb, d_workspace);
+    hipLaunchKernelGGL(col_sum_final_kernel, dim3((C + TB - 1) / TB), dim3(TB), 0, st, d_workspace, nrb, C, d_out, accumulate);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }

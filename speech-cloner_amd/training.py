@@ -88,7 +88,9 @@ class _Ops:
 
     @staticmethod
     def col_sum(X, M, Cn, ld, out, accumulate=0):
-        _vc.check(_lib().vc_col_sum(_p(X), M, Cn, ld, _p(out), int(accumulate), _st()))
+        torch = _torch()
+        ws = torch.empty(64 * Cn, dtype=torch.float32, device=X.device)
+        _vc.check(_lib().vc_col_sum(_p(X), M, Cn, ld, _p(out), int(accumulate), _p(ws), _st()))
 
 
 class DecoderTrainer:
