@@ -60,6 +60,9 @@ struct FeArgs {
     int32_t span;             // hop * (G - 1) + n_fft
 };
 
+// 10*log10(x) through v_log_f32 (1 ulp on log2): |error| < 3e-5 dB over the 100 dB range used here
+__device__ __forceinline__ float db10(float x) { return 3.0102999566398120f * __log2f(x); }
+
 __device__ __forceinline__ int utt_len(const FeArgs& a, int b) {
     int L = a.lens ? a.lens[b] : a.max_samples;
     return min(max(L, 1), a.max_samples);
@@ -96,23 +99,59 @@ __device__ __forceinline__ float amp_scale(const FeArgs& a, int b, int L) {
     return a.amp_norm / (t / (float)L);
 }
 
+// Memory-level parallelism: every global-memory loop below issues U independent loads per thread
+// before it consumes the first one (a load -> use -> store loop keeps one load per wave in
+// flight and runs at a fraction of the HBM rate; MI355X wants ~32 KiB in flight per CU).
+constexpr int FE_U = 8;
+
+// dst[i] = src[i] for i in [0, n): global -> LDS, batched
+__device__ __forceinline__ void copy_g2s(float* dst, const float* src, int n) {
+    for (int base = 0; base < n; base += FE_THREADS * FE_U) {
+        float v[FE_U];
+#pragma unroll
+        for (int u = 0; u < FE_U; ++u) {
+            const int i = base + u * FE_THREADS + threadIdx.x;
+            v[u] = src[min(i, n - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < FE_U; ++u) {
+            const int i = base + u * FE_THREADS + threadIdx.x;
+            if (i < n) dst[i] = v[u];
+        }
+    }
+}
+
 // Gather the samples a tile of frames needs into LDS: reflect padding of the pre-emphasised,
 // amplitude-normalised signal (np.pad(y_preem, n_fft//2, 'reflect') inside librosa.stft).
 __device__ __forceinline__ void load_tile(const FeArgs& a, int b, int L, int f0, float scale, float* xs) {
     const float* x = a.wav + (size_t)b * a.wav_stride;
     const int half = a.n_fft / 2;
     const int base = f0 * a.hop - half;
-    for (int i = threadIdx.x; i < a.span; i += FE_THREADS) {
-        const int idx = base + i;
-        float v = 0.0f;
-        if (idx < L + half) {
+    for (int i0 = 0; i0 < a.span; i0 += FE_THREADS * FE_U) {
+        float cur[FE_U], prev[FE_U];
+#pragma unroll
+        for (int u = 0; u < FE_U; ++u) {
+            const int idx = base + i0 + u * FE_THREADS + threadIdx.x;
             int j = idx < 0 ? -idx : (idx >= L ? 2 * (L - 1) - idx : idx);
             j = min(max(j, 0), L - 1);
-            const float cur = scale * x[j];
-            const float prev = (j > 0) ? scale * x[j - 1] : 0.0f;
-            v = (a.pre_emph != 0.0f) ? (cur - a.pre_emph * prev) : cur;
+            cur[u] = x[j];
+            prev[u] = x[max(j - 1, 0)];
         }
-        xs[i] = v;
+#pragma unroll
+        for (int u = 0; u < FE_U; ++u) {
+            const int i = i0 + u * FE_THREADS + threadIdx.x;
+            const int idx = base + i;
+            if (i < a.span) {
+                float v = 0.0f;
+                if (idx < L + half) {
+                    const int j = idx < 0 ? -idx : (idx >= L ? 2 * (L - 1) - idx : idx);
+                    const float c = scale * cur[u];
+                    const float pv = (j > 0) ? scale * prev[u] : 0.0f;
+                    v = (a.pre_emph != 0.0f) ? (c - a.pre_emph * pv) : c;
+                }
+                xs[i] = v;
+            }
+        }
     }
 }
 
@@ -129,7 +168,7 @@ __device__ __forceinline__ void power_epilogue(const FeArgs& a, int b, int f0, i
         const int total = nvalid * a.n_bins;
         for (int idx = tid; idx < total; idx += FE_THREADS) {
             const int g = idx / a.n_bins, k = idx - g * a.n_bins;
-            const float db = 10.0f * log10f(fmaxf(1e-10f, P[g * pstride + k]));
+            const float db = db10(fmaxf(1e-10f, P[g * pstride + k]));
             out[idx] = db;
             pmax = fmaxf(pmax, db);
             pmin = fminf(pmin, db);
@@ -146,7 +185,7 @@ __device__ __forceinline__ void power_epilogue(const FeArgs& a, int b, int f0, i
             for (int j = 0; j < cnt; ++j) acc = fmaf(melw[o + j], p[j], acc);
             // amplitude_to_db applied to the mel POWER (audio_lib.py:172):
             // 10 log10(max(1e-10, acc^2)) == 20 log10(max(1e-5, |acc|))
-            const float db = 20.0f * log10f(fmaxf(1e-5f, fabsf(acc)));
+            const float db = 2.0f * db10(fmaxf(1e-5f, fabsf(acc)));
             out[idx] = db;
             mmax = fmaxf(mmax, db);
             mmin = fminf(mmin, db);
@@ -177,9 +216,9 @@ __device__ __forceinline__ void write_neutral_stats(const FeArgs& a, int b) {
 
 // LDS carve shared by both power kernels: [mel weights | mel start | mel off | red(16) | ...]
 __device__ __forceinline__ void stage_mel(const FeArgs& a, float* melw, int32_t* mstart, int32_t* moff) {
-    for (int i = threadIdx.x; i < a.nnz; i += FE_THREADS) melw[i] = a.t.mel_w[i];
-    for (int i = threadIdx.x; i < a.n_mels; i += FE_THREADS) mstart[i] = a.t.mel_start[i];
-    for (int i = threadIdx.x; i <= a.n_mels; i += FE_THREADS) moff[i] = a.t.mel_off[i];
+    copy_g2s(melw, a.t.mel_w, a.nnz);
+    // mel_start | mel_off are adjacent in the plan blob and in LDS: one batched copy of 2*n_mels+1 words
+    copy_g2s(reinterpret_cast<float*>(mstart), reinterpret_cast<const float*>(a.t.mel_start), 2 * a.n_mels + 1);
 }
 
 // 400-point path: 16 frames per block, 256 threads.
@@ -207,8 +246,7 @@ fe_power400_kernel(FeArgs a) {
 
     const float scale = amp_scale(a, b, L);
     load_tile(a, b, L, f0, scale, xs);
-    for (int i = tid; i < 400; i += FE_THREADS) win[i] = a.t.window[i];
-    for (int i = tid; i < 416; i += FE_THREADS) tw[i] = a.t.tw400[i];
+    copy_g2s(win, a.t.window, 816);                     // window[400] | tw400[416] are adjacent in both
     stage_mel(a, melw, mstart, moff);
     __syncthreads();
 
@@ -271,7 +309,8 @@ fe_power_generic_kernel(FeArgs a) {
 
     const float scale = amp_scale(a, b, L);
     load_tile(a, b, L, f0, scale, xs);
-    for (int i = tid; i < N; i += FE_THREADS) { win[i] = a.t.window[i]; twc[i] = a.t.twg[i]; tws[i] = a.t.twg[N + i]; }
+    copy_g2s(win, a.t.window, N);
+    copy_g2s(twc, a.t.twg, 2 * N);                      // cos | -sin
     stage_mel(a, melw, mstart, moff);
     __syncthreads();
     // windowed frames in place is impossible (frames overlap) -> multiply inside the loop
@@ -298,12 +337,14 @@ __global__ void __launch_bounds__(FE_THREADS)
 fe_finalize_kernel(FeArgs a, int g2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int G = FE_G3;
-    const int NM = a.n_mels, NC = a.n_mfcc, DS = NM + 1;
-    float* D = reinterpret_cast<float*>(smem);         // [NC][NM+1]
-    float* Mc = D + NC * DS;                           // [G+2][NM]  top_db-clipped raw mel dB
-    float* Mf = Mc + (G + 2) * NM;                     // [G+2][NC]  scaled MFCC
-    float* M0 = Mf + (G + 2) * NC;                     // [NM] frame-0 clipped mel dB
-    float* sc = M0 + NM;                               // [8] scalars
+    const int NM = a.n_mels, NC = a.n_mfcc;
+    const int NM4 = (NM + 3) & ~3;                     // rows padded to float4 (pad = 0)
+    const int DS = NM4 + 4;                            // basis pitch: 16-B aligned, b128 conflict-free
+    float* D = reinterpret_cast<float*>(smem);         // [NC][DS]
+    float* Mc = D + NC * DS;                           // [G+2][NM4]  top_db-clipped raw mel dB
+    float* Mf = Mc + (G + 2) * NM4;                    // [G+2][NC]  scaled MFCC
+    float* M0 = Mf + (((G + 2) * NC + 3) & ~3);        // [NM4] frame-0 clipped mel dB
+    float* sc = M0 + NM4;                              // [8] scalars
 
     const int b = blockIdx.y, tid = threadIdx.x;
     const int L = utt_len(a, b);
@@ -340,9 +381,19 @@ fe_finalize_kernel(FeArgs a, int g2) {
             sc[2] = mfloor; sc[3] = fmaxf(mmin, mfloor);
         }
     }
-    for (int i = tid; i < NC * NM; i += FE_THREADS) {
-        const int r = i / NM, c = i - r * NM;
-        D[r * DS + c] = a.t.dct[i];
+    for (int base = 0; base < NC * DS; base += FE_THREADS * FE_U) {
+        float v[FE_U];
+#pragma unroll
+        for (int u = 0; u < FE_U; ++u) {
+            const int i = min(base + u * FE_THREADS + tid, NC * DS - 1);
+            const int r = i / DS, c = i - r * DS;
+            v[u] = a.t.dct[r * NM + min(c, NM - 1)];
+        }
+#pragma unroll
+        for (int u = 0; u < FE_U; ++u) {
+            const int i = base + u * FE_THREADS + tid;
+            if (i < NC * DS) D[i] = (i % DS) < NM ? v[u] : 0.0f;
+        }
     }
     __syncthreads();
     const float pfloor = sc[0], pmin_c = sc[1], mfloor = sc[2], mmin_c = sc[3];
@@ -353,28 +404,52 @@ fe_finalize_kernel(FeArgs a, int g2) {
     {
         float* o = a.pow_db + (row0 + f0) * a.n_bins;
         const int tv = nvalid * a.n_bins, tr = nrows * a.n_bins;
-        for (int i = tid; i < tr; i += FE_THREADS) {
-            float v = 0.0f;
-            if (i < tv) {
-                v = fmaxf(o[i], pfloor);
-                if (a.p_norm != 1.0f) v = a.p_norm * (v - pmin_c);
-                if (a.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
+        for (int base = 0; base < tr; base += FE_THREADS * FE_U) {
+            float v[FE_U];
+#pragma unroll
+            for (int u = 0; u < FE_U; ++u) v[u] = o[min(base + u * FE_THREADS + tid, tr - 1)];
+#pragma unroll
+            for (int u = 0; u < FE_U; ++u) {
+                const int i = base + u * FE_THREADS + tid;
+                if (i < tr) {
+                    float w = 0.0f;
+                    if (i < tv) {
+                        w = fmaxf(v[u], pfloor);
+                        if (a.p_norm != 1.0f) w = a.p_norm * (w - pmin_c);
+                        if (a.clip) w = fminf(fmaxf(w, -1.0f), 1.0f);
+                    }
+                    o[i] = w;
+                }
             }
-            o[i] = v;
         }
     }
     // mel dB tile with a one-frame halo each side (delta needs MFCC[t-1], MFCC[t+1])
     {
         const float* src = a.mel_raw + row0 * NM;
-        for (int i = tid; i < (G + 2) * NM; i += FE_THREADS) {
-            const int r = i / NM, c = i - r * NM;
-            const int f = f0 - 1 + r;
-            Mc[i] = (f >= 0 && f < F) ? fmaxf(src[(size_t)f * NM + c], mfloor) : 0.0f;
+        const int tot = (G + 2) * NM4;
+        for (int base = 0; base < tot; base += FE_THREADS * FE_U) {
+            float v[FE_U];
+#pragma unroll
+            for (int u = 0; u < FE_U; ++u) {
+                const int i = min(base + u * FE_THREADS + tid, tot - 1);
+                const int r = i / NM4, c = min(i - r * NM4, NM - 1);
+                const int f = min(max(f0 - 1 + r, 0), F - 1);
+                v[u] = src[(size_t)f * NM + c];
+            }
+#pragma unroll
+            for (int u = 0; u < FE_U; ++u) {
+                const int i = base + u * FE_THREADS + tid;
+                if (i < tot) {
+                    const int r = i / NM4, c = i - r * NM4;
+                    const int f = f0 - 1 + r;
+                    Mc[i] = (c < NM && f >= 0 && f < F) ? fmaxf(v[u], mfloor) : 0.0f;
+                }
+            }
         }
     }
     // frame 0's clipped mel row: its first cepstral coefficient is subtracted from every frame
     // (audio_lib.py:221)
-    for (int j = tid; j < NM; j += FE_THREADS) M0[j] = fmaxf(a.mel_raw[row0 * NM + j], mfloor);
+    for (int j = tid; j < NM4; j += FE_THREADS) M0[j] = j < NM ? fmaxf(a.mel_raw[row0 * NM + j], mfloor) : 0.0f;
     __syncthreads();
     {
         float* o = a.mel_db + (row0 + f0) * NM;
@@ -382,7 +457,7 @@ fe_finalize_kernel(FeArgs a, int g2) {
         for (int i = tid; i < tr; i += FE_THREADS) {
             float v = 0.0f;
             if (i < tv) {
-                v = Mc[NM + i];
+                v = Mc[(i / NM + 1) * NM4 + (i % NM)];
                 if (a.m_norm != 1.0f) v = a.m_norm * (v - mmin_c);
                 if (a.clip) v = fminf(fmaxf(v, -1.0f), 1.0f);
             }
@@ -390,17 +465,30 @@ fe_finalize_kernel(FeArgs a, int g2) {
         }
     }
     // DCT-II (audio_lib.py:176-179) + first-coefficient shift + scale (:220-224)
+    typedef float f4 __attribute__((ext_vector_type(4)));
     for (int i = tid; i < (G + 2) * NC; i += FE_THREADS) {
         const int r = i / NC, c = i - r * NC;
-        const float* d = D + c * DS;
-        const float* m = Mc + r * NM;
-        float acc = 0.0f;
-        for (int j = 0; j < NM; ++j) acc = fmaf(d[j], m[j], acc);
+        const f4* d = reinterpret_cast<const f4*>(D + c * DS);
+        const f4* m = reinterpret_cast<const f4*>(Mc + r * NM4);
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;      // float4 LDS reads, 4 independent chains
+#pragma unroll 4
+        for (int j = 0; j < NM4 / 4; ++j) {
+            const f4 dv = d[j], mv = m[j];
+            a0 = fmaf(dv[0], mv[0], a0); a1 = fmaf(dv[1], mv[1], a1);
+            a2 = fmaf(dv[2], mv[2], a2); a3 = fmaf(dv[3], mv[3], a3);
+        }
+        float acc = (a0 + a1) + (a2 + a3);
         if (c == 0 && a.first_mfcc) {
-            // same FMA chain on frame 0 => frame 0's own coefficient cancels to exactly 0
-            float c0 = 0.0f;
-            for (int j = 0; j < NM; ++j) c0 = fmaf(d[j], M0[j], c0);
-            acc -= c0;
+            // identical summation order on frame 0 => frame 0's own coefficient cancels to exactly 0
+            const f4* m0 = reinterpret_cast<const f4*>(M0);
+            float b0 = 0.0f, b1 = 0.0f, b2 = 0.0f, b3 = 0.0f;
+#pragma unroll 4
+            for (int j = 0; j < NM4 / 4; ++j) {
+                const f4 dv = d[j], mv = m0[j];
+                b0 = fmaf(dv[0], mv[0], b0); b1 = fmaf(dv[1], mv[1], b1);
+                b2 = fmaf(dv[2], mv[2], b2); b3 = fmaf(dv[3], mv[3], b3);
+            }
+            acc -= (b0 + b1) + (b2 + b3);
         }
         if (a.mfcc_norm != 1.0f) acc *= a.mfcc_norm;
         Mf[i] = acc;
@@ -675,7 +763,8 @@ int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, con
     }
     if (stage_mask & 4) {
         const int nt3 = (max_frames + FE_G3 - 1) / FE_G3;
-        const size_t lds = ((size_t)c.n_mfcc * (c.n_mels + 1) + (size_t)(FE_G3 + 2) * (c.n_mels + c.n_mfcc) + c.n_mels + 8) * 4;
+        const size_t nm4 = ((size_t)c.n_mels + 3) & ~(size_t)3;
+        const size_t lds = ((size_t)c.n_mfcc * (nm4 + 4) + (size_t)(FE_G3 + 2) * (nm4 + c.n_mfcc) + 4 + nm4 + 8) * 4;
         VC_REQUIRE(lds <= 160 * 1024, "n_mels/n_mfcc too large for the finalize kernel's LDS tile (%zu B)", lds);
         hipLaunchKernelGGL(fe_finalize_kernel, dim3(nt3, batch), dim3(FE_THREADS), lds, st, a, G);
     }
