@@ -8,7 +8,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libvc_hip.so')
+LIB_PATH = os.environ.get('VC_LIB_PATH', os.path.join(_HERE, 'libvc_hip.so'))   # override: kernel A/B experiments
 
 VC_OK = 0
 

@@ -365,8 +365,13 @@ gemm_kernel(KArgs a) {
 // the 128 x 128 bf16 tile is otherwise L2->LDS bandwidth bound.
 // The zeros of TF's SAME padding depend on (output row, tap), not on the LDS row, so they are
 // applied as a select on the fragment after the ds_read (lane i owns output rows with fixed t).
+// LDS image: the padded 144-byte rows of gemm_kernel (a third resident block per CU from an
+// unpadded XOR-swizzled image measured no faster, and the padded form keeps every fragment
+// address = one per-slab base + compile-time immediates).
 constexpr int CONV_MAX_TAPS = 32;
-constexpr int conv_lds_bytes() { return (128 + CONV_MAX_TAPS - 1) * ROWB + 2 * BN * ROWB; }   // A | B0 B1
+constexpr int CROWB = ROWB;
+constexpr int conv_lds_bytes() { return (128 + CONV_MAX_TAPS - 1) * CROWB + 2 * BN * CROWB; }   // A | B0 B1
+__device__ __forceinline__ int swz(int row, int chunk) { return row * CROWB + (chunk << 4); }
 
 template <typename T, int PRO>
 __global__ void __launch_bounds__(GEMM_THREADS, 2)
@@ -374,7 +379,7 @@ conv_kernel(KArgs a) {
     typedef typename Tr<T>::vec_t vec_t;
     constexpr int VEC = Tr<T>::VEC, BK = Tr<T>::BK;      // BK = channels per slab
     constexpr int BM = 128, MI = 2;
-    constexpr int A_BYTES = (BM + CONV_MAX_TAPS - 1) * ROWB, B_BYTES = BN * ROWB;
+    constexpr int A_BYTES = (BM + CONV_MAX_TAPS - 1) * CROWB, B_BYTES = BN * CROWB;
     constexpr int NAP = 5;                                // ceil((128 + 31) * 8 / 256) staging passes
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const As = smem;
@@ -427,7 +432,8 @@ conv_kernel(KArgs a) {
         jhi[mi] = min(taps, Tn - t + pad_l);
     }
 
-    vec_t ra[NAP], ra2[PRO >= 1 ? NAP : 1], rb[4];
+    vec_t ra[NAP], ra2[PRO >= 1 ? NAP : 1];
+    vec_t rbE[4], rbO[4];                                // B register sets of even / odd slabs
     auto gloadA = [&](int cs) {
         const int c = cs * BK;
 #pragma unroll
@@ -447,20 +453,29 @@ conv_kernel(KArgs a) {
                 if (PRO == 2) v2 = pro_apply(v2, a.pro_scale, a.pro_shift, c, a.pro_relu);
                 if (pool) v = nonneg ? vmax_nonneg(v, v2) : vmax(v, v2);
             }
-            if (a_in[p]) *reinterpret_cast<vec_t*>(As + (sr + 32 * p) * ROWB + sc * 16) = v;
+            if (a_in[p]) *reinterpret_cast<vec_t*>(As + swz(sr + 32 * p, sc)) = v;
         }
     };
-    auto gloadB = [&](int cs, int j) {
-        const int kb = j * Cin + cs * BK;
+    // B loads run TWO slabs ahead of the MFMAs: a tile that arrives from L2 / Infinity Cache takes
+    // longer than one slab of matrix work (16 MFMAs = 512 cycles per wave).
+    int l_cs = 0, l_j = 0;                               // (channel slab, tap) of the next B slab to load
+    auto gloadB = [&](vec_t* rb) {
+        const int kb = l_j * Cin + l_cs * BK;
 #pragma unroll
         for (int p = 0; p < 4; ++p) rb[p] = *reinterpret_cast<const vec_t*>(b_row[p] + kb);
+        if (++l_j == taps) { l_j = 0; ++l_cs; }
     };
-    auto lstoreB = [&](int buf) {
-        char* Bs = Bs0 + buf * B_BYTES;
+    const bool full_n = n0 + BN <= a.N;                   // block-uniform: no B row needs zeroing
+    auto lstoreB = [&](int buf, const vec_t* rb) {
+        char* Bs = Bs0 + buf * B_BYTES + sr * CROWB + sc * 16;
         const vec_t zero = {};
+        if (full_n) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
-            *reinterpret_cast<vec_t*>(Bs + (sr + 32 * p) * ROWB + sc * 16) = b_ok[p] ? rb[p] : zero;
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<vec_t*>(Bs + 32 * p * CROWB) = rb[p];
+        } else {
+#pragma unroll
+            for (int p = 0; p < 4; ++p) *reinterpret_cast<vec_t*>(Bs + 32 * p * CROWB) = b_ok[p] ? rb[p] : zero;
+        }
     };
 
     f32x16 acc[MI][2];
@@ -471,34 +486,35 @@ conv_kernel(KArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
-    gloadA(0);
-    gloadB(0, 0);
-    lstoreA(0);
-    lstoreB(0);
-    __syncthreads();
     const int nit = ncs * taps;
+    gloadA(0);
+    gloadB(rbE);                                         // slab 0
+    if (nit > 1) gloadB(rbO);                            // slab 1
+    lstoreA(0);
+    lstoreB(0, rbE);
+    __syncthreads();
     int cs = 0, j = 0;
-    for (int it = 0; it < nit; ++it) {
-        int cs_n = cs, j_n = j + 1;
-        if (j_n == taps) { j_n = 0; cs_n = cs + 1; }
-        const bool more = it + 1 < nit;
-        if (more) gloadB(cs_n, j_n);
+    auto body = [&](int it, vec_t* rb_load, const vec_t* rb_store) {
+        // rb_load: set of slab `it` (already in LDS) -> refilled with slab it+2;  rb_store: slab it+1
+        if (it + 2 < nit) gloadB(rb_load);
         const bool stageA = (j == 0) && (cs + 1 < ncs);   // next channel slab's tile: long flight
         if (stageA) gloadA(cs + 1);
         {   // MFMAs of slab (cs, j): A fragment = resident tile shifted down by j rows
-            const char* Bs = Bs0 + (it & 1) * B_BYTES;
-            const char* ap = As + (wm * 64 + li + j) * ROWB + lh * 16;
-            const char* bp = Bs + (wn * 64 + li) * ROWB + lh * 16;
+            const char* ap = As + (wm * 64 + li + j) * CROWB + lh * 16;     // tile shifted down by j rows
+            const char* bp = Bs0 + (it & 1) * B_BYTES + (wn * 64 + li) * CROWB + lh * 16;
             const bool v0 = j >= jlo[0] && j < jhi[0], v1 = j >= jlo[1] && j < jhi[1];
+            const bool all_valid = __all(v0 && v1);           // wave-uniform: no SAME-padding zero in this wave's rows
             const vec_t zero = {};
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
                 vec_t av0 = *reinterpret_cast<const vec_t*>(ap + s4 * 32);
-                vec_t av1 = *reinterpret_cast<const vec_t*>(ap + 32 * ROWB + s4 * 32);
+                vec_t av1 = *reinterpret_cast<const vec_t*>(ap + 32 * CROWB + s4 * 32);
                 const vec_t bv0 = *reinterpret_cast<const vec_t*>(bp + s4 * 32);
-                const vec_t bv1 = *reinterpret_cast<const vec_t*>(bp + 32 * ROWB + s4 * 32);
-                av0 = v0 ? av0 : zero;
-                av1 = v1 ? av1 : zero;
+                const vec_t bv1 = *reinterpret_cast<const vec_t*>(bp + 32 * CROWB + s4 * 32);
+                if (!all_valid) {
+                    av0 = v0 ? av0 : zero;
+                    av1 = v1 ? av1 : zero;
+                }
                 if constexpr (sizeof(T) == 2) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av0, bv0, acc[0][0], 0, 0, 0);
                     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av0, bv1, acc[0][1], 0, 0, 0);
@@ -519,10 +535,13 @@ conv_kernel(KArgs a) {
             __syncthreads();
             lstoreA(cs + 1);
         }
-        if (more) lstoreB((it + 1) & 1);
+        if (it + 1 < nit) lstoreB((it + 1) & 1, rb_store);
         __syncthreads();
-        cs = cs_n;
-        j = j_n;
+        if (++j == taps) { j = 0; ++cs; }
+    };
+    for (int it = 0; it < nit; it += 2) {
+        body(it, rbE, rbO);
+        if (it + 1 < nit) body(it + 1, rbO, rbE);
     }
 
     // ---------------------------------------------------------------------------- epilogue

@@ -1,0 +1,43 @@
+#!/usr/bin/env python
+"""Runs the dominant kernels of the hot path a few times each, stand-alone, so rocprofv3 (kernel
+trace or --pmc passes) sees clean dispatches:  python tools/prof_kernels.py [bank|proj1|gru|frontend|all]
+
+Shapes = the bench's full workload (64 windows x 400 frames, decoder step 2, bf16; front-end on
+32 x 4 s).  Prints the algorithmic bytes / FLOPs per launch used by bench.py's roofline."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'speech-cloner_amd')):
+    sys.path.insert(0, p)
+import torch          # noqa: E402
+import modules        # noqa: E402
+import audio_lib      # noqa: E402
+import bench          # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+W, T, reps = 64, 400, 3
+st = modules.VariableStore('bfloat16')
+torch.manual_seed(0)
+with modules.variable_store(st), modules.variable_scope('decoder'), modules.variable_scope('step2'), modules.variable_scope('CBHG'):
+    pre = torch.randn(W, T, 256, device='cuda').to(st.dtype)
+    if what in ('bank', 'all', 'proj1'):
+        for _ in range(reps):
+            bank = modules.conv1d_banks(pre, K=32, is_training=False)
+    if what in ('proj1', 'all'):
+        for _ in range(reps):
+            modules.conv1d(bank, filters=256, size=3, scope="conv1d_1", bn_scope="conv1d_1", activation_fn='relu', pool_input=2)
+    if what in ('gru', 'all'):
+        for _ in range(reps):
+            modules.gru(pre, num_units=256, bidirection=True)
+if what in ('frontend', 'all'):
+    wav = bench.synth_audio(32, 64000, 0).cuda()
+    out = None
+    for _ in range(reps):
+        out = audio_lib.calc_MFCC_input_batch(wav, None, out=out, **bench.FE_KW)
+torch.cuda.synchronize()
+print('bank  : %.4g FLOP/launch ; operands: X %d B + W %d B, out %d B' % (
+    2.0 * 256 * 128 * 528 * W * T, W * T * 256 * 2, 256 * 128 * 528 * 2, W * T * 4096 * 2))
+print('proj1 : %.4g FLOP/launch ; in %d B (x3 taps x2 pool via L2), W %d B, out %d B' % (
+    2.0 * 3 * 4096 * 256 * W * T, W * T * 4096 * 2, 3 * 4096 * 256 * 2, W * T * 256 * 2))
+print('front : %d B/launch algorithmic (1,764 B/frame x 25,632 frames)' % (1764 * 25632))
