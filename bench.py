@@ -200,9 +200,18 @@ def bench_full(args, rank, world):
         ms_enc = time_events(lambda: enc.forward(x), 5)
         ms_all = time_events(lambda: dec.forward(x), 5)
         ach = fl_bank / (ms_bank * 1e-3) / 1e12
-        extra['roofline'] = {'kernel': 'gemm_kernel<%s> (decoder step2 conv1d_banks, 32 groups)' % args.dtype,
+        # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes
+        # (profiles/r01/pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 correction)
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_summary.json')))
+            if args.dtype == 'bfloat16' and W == 64:
+                traffic = pm['conv_kernel_bf16_bank_step2']['traffic_bytes_per_launch']
+        except Exception:
+            traffic = None
+        extra['roofline'] = {'kernel': 'conv_kernel<%s> (decoder step2 conv1d_banks, 32 groups)' % args.dtype,
                              'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
-                             'frac': round(ach / peak, 4), 'traffic': None,
+                             'frac': round(ach / peak, 4), 'traffic': traffic,
                              'algorithmic_flop_per_launch': fl_bank, 'avg_kernel_ms': round(ms_bank, 4)}
         extra['stages'] = {
             'frontend_ms': round(ms_fe, 4), 'frontend_frames_per_s': round(B * (1 + L // 80) / (ms_fe * 1e-3), 1),

@@ -224,7 +224,9 @@ int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw,
  *   dW[j*Cin + c, o] = sum_m X[m + j + shift0, c] * dY[m, o]    (shift0 = -pad_l; a frame of
  *   another window contributes nothing).  Operands are TRANSPOSED, frames contiguous, built by
  *   vc_transpose_pad with a zero margin of `margin` frames on both sides of every row:
- *   d_XT [Cin, ldxt], d_dYT rows [N, ldyt]; both pointers address frame 0.  Groups = the banks. */
+ *   d_XT [Cin, ldxt], d_dYT rows [N, ldyt]; both pointers address frame 0; the allocations carry
+ *   one slack row after the last (a shifted tail read may run `margin` frames past it).
+ *   Groups = the banks. */
 typedef struct vc_wgrad_group {
     const void* d_dYT;
     void* d_dW;

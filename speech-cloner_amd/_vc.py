@@ -126,6 +126,10 @@ def lib():
             raise VCError('native library %s not found -- run `python -c "import __graft_entry__ as g; '
                           'g.build()"` (or make -C speech-cloner_amd/csrc); there is no CPU fallback'
                           % LIB_PATH)
+        # torch ships its own libamdhip64; it must be the HIP runtime of the process.  Loading this
+        # library first would pull in the system copy and leave two runtimes ("no ROCm-capable
+        # device" from the second one), so torch is imported before the dlopen.
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(h, name)

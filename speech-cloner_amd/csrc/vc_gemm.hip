@@ -643,11 +643,11 @@ wgrad_kernel(WArgs a) {
     int g_m = 0;                                          // first frame of the next slab to load
     int st_m = 0;
     auto gload = [&]() {
-        const int mm = min(g_m, max(M - 32, 0));          // keep the addresses inside the margin
+        // a tail slab (M % 32 != 0) reads up to 31 frames past M: inside the operands' zero margin
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
-            ra[p] = *reinterpret_cast<const f32x4u*>(a_base[p] + mm);
-            rb[p] = *reinterpret_cast<const f32x4u*>(b_base[p] + mm);
+            ra[p] = *reinterpret_cast<const f32x4u*>(a_base[p] + g_m);
+            rb[p] = *reinterpret_cast<const f32x4u*>(b_base[p] + g_m);
         }
         st_m = g_m;
         g_m += BK;
@@ -656,7 +656,7 @@ wgrad_kernel(WArgs a) {
         char* As = smem + buf * BUF_BYTES;
         char* Bs = As + A_BYTES;
         const int m = st_m + sc * 4;
-        const bool exact = st_m <= max(M - 32, 0);        // clamped tail slab: treat as empty (M % 32 == 0 in practice)
+        const bool exact = true;
         const int t0 = m % Tn;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
@@ -788,9 +788,8 @@ extern "C" int vc_conv_gemm(const vc_gemm_desc* d, void* stream) {
 extern "C" int vc_conv_wgrad(const vc_wgrad_desc* d, void* stream) {
     VC_REQUIRE(d != nullptr && d->d_XT != nullptr, "NULL desc / XT");
     VC_REQUIRE(d->Cin > 0 && d->M > 0 && d->T > 0 && d->M % d->T == 0 && d->T % 4 == 0, "bad shape Cin=%d M=%d T=%d", d->Cin, d->M, d->T);
-    VC_REQUIRE(d->M % 32 == 0, "M (%d) must be a multiple of 32", d->M);
     VC_REQUIRE(d->n_groups >= 1 && d->n_groups <= VC_GEMM_MAX_GROUPS, "n_groups out of range");
-    VC_REQUIRE(d->margin >= 32, "operand margin must be >= 32 frames");
+    VC_REQUIRE(d->margin >= 32, "operand margin must be >= 32 frames (and one slack row after the last)");
     WArgs wa;
     wa.XT = d->d_XT; wa.ldxt = d->ldxt; wa.ldyt = d->ldyt; wa.Cin = d->Cin; wa.M = d->M; wa.T = d->T; wa.n_groups = d->n_groups;
     int max_tiles = 0;

@@ -205,6 +205,7 @@ gru_resident_kernel(GruArgs a, const WT* packed) {
     constexpr int NC1 = KL1 / EPC, NC2 = KL2 / EPC;
     constexpr int P = EPC;                                   // 16-byte pad between K-slices
     static_assert(KS1 >= 1 && KS2 <= 64 && KL1 % EPC == 0 && KL2 % EPC == 0, "unsupported H");
+    static_assert(2 * H <= NT, "one thread per gate column at least");
     __shared__ __attribute__((aligned(16))) hs_t hb[KS1 * (KL1 + P)];     // h, sliced for phase 1
     __shared__ __attribute__((aligned(16))) hs_t rhb[KS2 * (KL2 + P)];    // r*h, sliced for phase 2
     __shared__ float hf[H];                                               // h in f32 (for r*h)
@@ -249,7 +250,7 @@ gru_resident_kernel(GruArgs a, const WT* packed) {
 #pragma unroll
         for (int o = KS1 >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
         if (ks1 == 0) {
-            const float g = sigmoidf_(acc + xg);
+            const float g = (sizeof(WT) == 2) ? fast_sigmoid(acc + xg) : sigmoidf_(acc + xg);
             if (col1 < H) {
                 const int s = col1 / KL2, off = col1 - s * KL2;
                 rhb[s * (KL2 + P) + off] = (hs_t)(g * hf[col1]);
@@ -265,7 +266,7 @@ gru_resident_kernel(GruArgs a, const WT* packed) {
 #pragma unroll
         for (int o = KS2 >> 1; o > 0; o >>= 1) acc2 += __shfl_xor(acc2, o, 64);
         if (ks2 == 0) {
-            const float c = tanhf(acc2 + xc);
+            const float c = (sizeof(WT) == 2) ? fast_tanh(acc2 + xc) : tanhf(acc2 + xc);
             const float uu = ul[col2];
             const float hn = uu * hreg + (1.0f - uu) * c;
             hreg = hn;
@@ -500,7 +501,7 @@ int launch_mfma(const GruArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 template <int H, typename WT>
 __global__ void __launch_bounds__(64)
 gru_wave_kernel(GruArgs a) {
-    static_assert(H <= 64, "one lane per hidden unit");
+    static_assert(H <= 64 && H % 4 == 0, "one lane per hidden unit, unrolled by 4");
     constexpr int H3 = 3 * H;
     const int lane = threadIdx.x;
     const int seq = blockIdx.x, dir = blockIdx.y;
@@ -526,22 +527,36 @@ gru_wave_kernel(GruArgs a) {
             const float* xn = xbase + (size_t)(t + dt) * xrow;
             xr_n = xn[0]; xu_n = xn[H]; xc_n = xn[2 * H];
         }
-        float ar = xr, au = xu;
+        // two partial sums per gate (four for the candidate): the FMA chains, not the issue rate,
+        // bound a single wave
+        float ar0 = xr, ar1 = 0.0f, au0 = xu, au1 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < H; ++k) {
-            const float hk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k));
-            ar = fmaf(hk, wr[k], ar);
-            au = fmaf(hk, wu[k], au);
+        for (int k = 0; k < H; k += 2) {
+            const float h0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k));
+            const float h1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(h), k + 1));
+            ar0 = fmaf(h0, wr[k], ar0);
+            au0 = fmaf(h0, wu[k], au0);
+            ar1 = fmaf(h1, wr[k + 1], ar1);
+            au1 = fmaf(h1, wu[k + 1], au1);
         }
-        const float r = sigmoidf_(ar), u = sigmoidf_(au);
+        constexpr bool FAST = sizeof(WT) == 2;            // bf16 model: v_exp/v_rcp gate functions
+        const float r = FAST ? fast_sigmoid(ar0 + ar1) : sigmoidf_(ar0 + ar1);
+        const float u = FAST ? fast_sigmoid(au0 + au1) : sigmoidf_(au0 + au1);
         const float rh = r * h;
-        float ac = xc;
+        float ac0 = xc, ac1 = 0.0f, ac2 = 0.0f, ac3 = 0.0f;
 #pragma unroll
-        for (int k = 0; k < H; ++k) {
-            const float rk = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rh), k));
-            ac = fmaf(rk, wc[k], ac);
+        for (int k = 0; k < H; k += 4) {
+            const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rh), k));
+            const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rh), k + 1));
+            const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rh), k + 2));
+            const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(rh), k + 3));
+            ac0 = fmaf(r0, wc[k], ac0);
+            ac1 = fmaf(r1, wc[k + 1], ac1);
+            ac2 = fmaf(r2, wc[k + 2], ac2);
+            ac3 = fmaf(r3, wc[k + 3], ac3);
         }
-        const float c = tanhf(ac);
+        const float acs = (ac0 + ac1) + (ac2 + ac3);
+        const float c = FAST ? fast_tanh(acs) : tanhf(acs);
         h = act ? (u * h + (1.0f - u) * c) : 0.0f;
         if (act) st_out<WT>(a.out, ((size_t)seq * a.T + t) * 2 * H + (size_t)dir * H + j, h, a.out_bf16);
         xr = xr_n; xu = xu_n; xc = xc_n;
@@ -625,8 +640,9 @@ int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw,
     static const bool use_valu = (getenv("VC_GRU_MFMA") == nullptr);
     if (w_dtype == VC_BF16 && H == 256) return use_valu ? launch_resident<256, __bf16, 512>(a, d_workspace, workspace_bytes, st)
                                                         : launch_mfma<256>(a, d_workspace, workspace_bytes, st);
-    if (w_dtype == VC_BF16 && H == 128) return use_valu ? launch_resident<128, __bf16, 1024>(a, d_workspace, workspace_bytes, st)
+    if (w_dtype == VC_BF16 && H == 128) return use_valu ? launch_resident<128, __bf16, 256>(a, d_workspace, workspace_bytes, st)
                                                         : launch_mfma<128>(a, d_workspace, workspace_bytes, st);
+    // (H = 128 runs 256 threads: four fat waves beat sixteen thin ones, the step is barrier-bound)
     if (w_dtype == VC_F32 && H == 128) return launch_resident<128, float, 1024>(a, d_workspace, workspace_bytes, st);
     if (H == 40) {                                      // the shipped encoder (hp/encoder_cfg_d.json)
         if (w_dtype == VC_F32) hipLaunchKernelGGL((gru_wave_kernel<40, float>), grid, dim3(64), 0, st, a);

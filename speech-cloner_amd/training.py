@@ -49,7 +49,7 @@ class _Ops:
         """-> (buffer [Cn, M + 2*MARGIN] zero-initialised, ldt).  Data starts at column MARGIN."""
         torch = _torch()
         ldt = M + 2 * MARGIN
-        buf = torch.zeros((Cn, ldt), dtype=torch.float32, device=X.device)
+        buf = torch.zeros((Cn + 1, ldt), dtype=torch.float32, device=X.device)    # + one slack row
         _vc.check(_lib().vc_transpose_pad(_p(X), M, Cn, ld, T, _p(scale), _p(shift), int(relu), int(pool),
                                           int(row_shift), _p(buf), ldt, MARGIN, _st()))
         return buf, ldt

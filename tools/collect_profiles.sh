@@ -1,0 +1,45 @@
+#!/bin/bash
+# Collects the round's evidence on the GPU box into gpurun_out/r01 (copied to profiles/r01 afterwards).
+# usage: bash tools/collect_profiles.sh     (from the repo root, on the MI355X box)
+set -o pipefail
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r01
+mkdir -p $O
+cd $R
+timeout -k 10 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log
+timeout -k 10 300 python bench.py > $O/bench_full.log 2>&1
+timeout -k 10 200 python bench.py --workload frontend --steps 50 --warmup 5 > $O/bench_frontend.log 2>&1
+timeout -k 10 300 python bench.py --workload train --steps 3 --warmup 1 > $O/bench_train.log 2>&1
+timeout -k 10 200 python bench.py --dtype float32 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_full_f32.log 2>&1
+cd /tmp && export TMPDIR=/tmp
+for W in full frontend train; do
+  EXTRA="--steps 5 --warmup 1 --no-cpu-baseline"; [ $W = train ] && EXTRA="--steps 2 --warmup 1"
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$W -- python3 $R/bench.py --workload $W $EXTRA > $O/trace_$W.log 2>&1
+  cp $O/trace_$W/*/*kernel_stats.csv $O/${W}_kernel_stats.csv 2>/dev/null
+done
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+  N=$(echo $C | tr " " "_" | cut -c1-20)
+  timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$N -- python3 $R/tools/prof_kernels.py all > $O/pmc_$N.log 2>&1
+done
+python3 - <<PY
+import csv, glob, collections, json
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+names = {'conv_kernelIDF16bLi0': 'conv_kernel_bf16_bank_step2', 'conv_kernelIDF16bLi1': 'conv_kernel_bf16_proj1_step2',
+         'gru_resident_kernelILi256': 'gru_resident_256', 'fe_power400': 'fe_power400_kernel',
+         'fe_finalize': 'fe_finalize_kernel', 'fe_abssum': 'fe_abssum_kernel'}
+for f in glob.glob('$O/pmc_*/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        for k, v in names.items():
+            if k in r['Kernel_Name']:
+                agg[v][r['Counter_Name']].append(float(r['Counter_Value']))
+out = {}
+for k, v in agg.items():
+    d = {c: sum(x) / len(x) for c, x in v.items()}
+    if 'FETCH_SIZE' in d and 'WRITE_SIZE' in d:
+        # MI355X_MICROARCH.md: FETCH_SIZE/WRITE_SIZE are KiB; FETCH_SIZE reads 1/2 of a wide coalesced stream on gfx950
+        d['traffic_bytes_per_launch'] = int((2 * d['FETCH_SIZE'] + d['WRITE_SIZE']) * 1024)
+    out[k] = d
+json.dump(out, open('$O/pmc_summary.json', 'w'), indent=1, sort_keys=True)
+print(json.dumps({k: v.get('traffic_bytes_per_launch') for k, v in out.items()}))
+PY
+tail -2 $O/smoke.log; for f in bench_full bench_frontend bench_train bench_full_f32; do tail -1 $O/$f.log | cut -c1-330; done
