@@ -157,13 +157,35 @@ def bench_full(args, rank, world):
     fe_out = None
     res = {}
 
+    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
+    chunk_no = [0]
+
     def step():
         nonlocal fe_out
         fe_out = audio_lib.calc_MFCC_input_batch(wav, None, out=fe_out, **FE_KW)
         x = fe_out[0][:, :2 * T, :].reshape(nwin, T, 80)
+        if streams is None:
+            for i in range(0, nwin, args.window_batch):
+                o = dec.forward(x[i:i + args.window_batch].contiguous())
+                res[i] = (o['y_mel'], o['y_stft'], o['y_phn'])
+            return
+        # independent window chunks on separate HIP streams: one chunk's latency-bound recurrences
+        # (<= 128 workgroups) overlap with another chunk's GEMMs
+        # (consecutive steps are independent batches, so they also alternate streams: step i+1's
+        # front-end and GEMMs run under step i's recurrences; everything is joined by the
+        # synchronize() that closes the timed region)
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
         for i in range(0, nwin, args.window_batch):
-            o = dec.forward(x[i:i + args.window_batch].contiguous())
-            res[i] = (o['y_mel'], o['y_stft'], o['y_phn'])
+            st_ = streams[chunk_no[0] % len(streams)]
+            chunk_no[0] += 1
+            st_.wait_event(ready)
+            with torch.cuda.stream(st_):
+                xi = x[i:i + args.window_batch].contiguous()
+                xi.record_stream(st_)
+                o = dec.forward(xi)
+                res[(i, chunk_no[0] % (2 * len(streams)))] = (o['y_mel'], o['y_stft'], o['y_phn'])
 
     for _ in range(args.warmup):
         step()
@@ -224,8 +246,9 @@ def bench_full(args, rank, world):
             'model_TFLOPs_end_to_end': round((ENC_FLOP_PER_FRAME + DEC_FLOP_PER_FRAME) * W * T / (ms_all * 1e-3) / 1e12, 2)}
     cfg = {'workload': 'full: STFT+mel front-end on batch 32 x 4 s @ 16 kHz (configs[1] input) -> 64 windows of 400 '
                        'frames -> encoder (enc_14 weights) + decoder (hp/decoder_cfg_d.json sizes, random init), '
-                       '%d windows per launch' % args.window_batch,
-           'batch': B, 'samples': L, 'windows': nwin, 'frames_per_step_per_gpu': frames, 'model_dtype': args.dtype}
+                       '%d windows per launch, independent steps pipelined over %d HIP streams' % (args.window_batch, args.streams),
+           'batch': B, 'samples': L, 'windows': nwin, 'frames_per_step_per_gpu': frames, 'model_dtype': args.dtype,
+           'streams': args.streams}
     return frames, dt, extra, cfg
 
 
@@ -332,6 +355,8 @@ def main():
     ap.add_argument('--workload', default='full', choices=['full', 'frontend', 'train'])
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
     ap.add_argument('--window-batch', type=int, default=64)
+    ap.add_argument('--streams', type=int, default=3,
+                    help='HIP streams the independent window chunks / consecutive steps are pipelined over')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     args = ap.parse_args()
 

@@ -207,13 +207,34 @@ class decoder_specs:
     def _input_width(self):
         return self.encoder.cfg_d['input_shape'][-1] if self.encoder is not None else self.cfg_d['input_shape'][-1]
 
-    def predict(self, x, batch_size=32):
+    def predict(self, x, batch_size=32, n_streams=2):
         """decoder.py:447-465: chunks of ``batch_size`` windows; returns the namedtuple
-        (y_mel [N,T,n_mels], y_stft [N,T,n_stft], y_phn [N,T,n_in]) as numpy float32."""
-        y_mel_v, y_stft_v, y_phn_v = [], [], []
-        for i_s in range(0, x.shape[0], batch_size):
+        (y_mel [N,T,n_mels], y_stft [N,T,n_stft], y_phn [N,T,n_in]) as numpy float32.
+        The chunks are independent, so they are issued round-robin on ``n_streams`` HIP streams:
+        one chunk's latency-bound recurrences overlap with another chunk's GEMMs (results are
+        identical to the sequential order)."""
+        import torch
+        n_chunks = (x.shape[0] + batch_size - 1) // batch_size
+        use_streams = n_streams > 1 and n_chunks > 1 and torch.cuda.is_available()
+        if use_streams and getattr(self, '_streams', None) is None:
+            self._streams = [torch.cuda.Stream() for _ in range(n_streams)]
+        outs = []
+        main = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        for k, i_s in enumerate(range(0, x.shape[0], batch_size)):
             x_batch = self._to_device(x[i_s:min(i_s + batch_size, x.shape[0])], self._input_width(), 'decoder input')
-            o = self.forward(x_batch)
+            if use_streams:
+                st = self._streams[k % len(self._streams)]
+                st.wait_stream(main)
+                with torch.cuda.stream(st):
+                    x_batch.record_stream(st)
+                    outs.append(self.forward(x_batch))
+            else:
+                outs.append(self.forward(x_batch))
+        if use_streams:
+            for st in self._streams:
+                main.wait_stream(st)
+        y_mel_v, y_stft_v, y_phn_v = [], [], []
+        for o in outs:
             y_mel_v.append(o['y_mel'].cpu().numpy())
             y_stft_v.append(o['y_stft'].cpu().numpy())
             y_phn_v.append(o['y_phn'].float().cpu().numpy())

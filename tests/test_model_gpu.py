@@ -135,3 +135,20 @@ def test_full_size_encode_decode_vs_oracle(golden_dir):
     for dev, ref, nm in ((r.y_mel, ym, 'y_mel'), (r.y_stft, ys, 'y_stft')):
         err = np.abs(dev - ref.numpy()).max()
         assert err < 1e-3, '%s err %.3e' % (nm, err)          # mel/stft abs 1e-3 f32
+
+
+def test_predict_stream_overlap_is_bit_identical(golden_dir):
+    """decoder.predict issues independent window chunks on several HIP streams; the outputs must
+    be exactly those of the sequential order."""
+    from encoder import encoder_spec_phn
+    from decoder import decoder_specs
+    g = np.load(os.path.join(golden_dir, 'encoder_fwd.npz'))
+    dec_cfg = json.load(open(os.path.join(HP, 'decoder_cfg_d.json')))
+    dec_cfg['is_training'] = False
+    enc = encoder_spec_phn(_enc_cfg(golden_dir, 'bfloat16'), None)
+    dec = decoder_specs(dec_cfg, None, enc)
+    x = np.concatenate([g['x'], g['x'][::-1] * 0.5, g['x'] * 0.25], 0)         # 9 windows -> 5 chunks of 2
+    a = dec.predict(x, batch_size=2, n_streams=1)
+    b = dec.predict(x, batch_size=2, n_streams=3)
+    for u_, v_ in zip(a, b):
+        assert np.array_equal(u_, v_)
