@@ -236,6 +236,8 @@ typedef struct vc_wgrad_group {
 typedef struct vc_wgrad_desc {
     const void* d_XT;
     int32_t ldxt, ldyt, Cin, M, T, margin, n_groups;
+    int32_t splits_allowed;   /* != 0: every d_dW is pre-zeroed and may be accumulated with float atomics
+                                 (the frame reduction is then split over more workgroups) */
     vc_wgrad_group groups[VC_GEMM_MAX_GROUPS];
 } vc_wgrad_desc;
 int vc_conv_wgrad(const vc_wgrad_desc* desc, void* stream);
@@ -290,9 +292,12 @@ int vc_adam_step(float* d_param, const float* d_grad, float* d_m, float* d_v, si
 int vc_gru_train_forward(const float* d_xproj, const float* d_Wh_fw, const float* d_Wh_bw, int32_t n_seq,
                          int32_t T, int32_t H, float* d_out, float* d_gates, float* d_rh, void* stream);
 /* BPTT of the above: d_dout [n_seq*T, 2H] -> d_dpre [n_seq*T, 6H] = gradient w.r.t. the gate
- * pre-activations in the layout of d_xproj (input/recurrent weight gradients follow as GEMMs). */
+ * pre-activations in the layout of d_xproj (input/recurrent weight gradients follow as GEMMs).
+ * d_WhT_* [3H, H]: optional transposed copies of the recurrent weights; with them several windows
+ * share a workgroup and the W^T matvecs read coalesced rows. */
 int vc_gru_backward(const float* d_dout, const float* d_out, const float* d_gates, const float* d_Wh_fw,
-                    const float* d_Wh_bw, int32_t n_seq, int32_t T, int32_t H, float* d_dpre, void* stream);
+                    const float* d_Wh_bw, const float* d_WhT_fw, const float* d_WhT_bw, int32_t n_seq,
+                    int32_t T, int32_t H, float* d_dpre, void* stream);
 
 /* float32 <-> bf16 conversion of a contiguous buffer (weights preparation, I/O). */
 int vc_convert(const void* d_src, int32_t src_dtype, void* d_dst, int32_t dst_dtype, size_t n, void* stream);

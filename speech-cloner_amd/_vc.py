@@ -63,7 +63,7 @@ class WgradDesc(C.Structure):
     """struct vc_wgrad_desc (include/vc_hip.h)."""
     _fields_ = [('d_XT', C.c_void_p), ('ldxt', C.c_int32), ('ldyt', C.c_int32), ('Cin', C.c_int32),
                 ('M', C.c_int32), ('T', C.c_int32), ('margin', C.c_int32), ('n_groups', C.c_int32),
-                ('groups', WgradGroup * GEMM_MAX_GROUPS)]
+                ('splits_allowed', C.c_int32), ('groups', WgradGroup * GEMM_MAX_GROUPS)]
 
 
 _lib = None
@@ -110,7 +110,7 @@ _SIGS = {
     'vc_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,
                                C.c_float, _P]),
     'vc_gru_train_forward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
-    'vc_gru_backward': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    'vc_gru_backward': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
 }
 
 

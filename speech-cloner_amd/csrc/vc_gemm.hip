@@ -503,18 +503,26 @@ conv_kernel(KArgs a) {
             const char* ap = As + (wm * 64 + li + j) * CROWB + lh * 16;     // tile shifted down by j rows
             const char* bp = Bs0 + (it & 1) * B_BYTES + (wn * 64 + li) * CROWB + lh * 16;
             const bool v0 = j >= jlo[0] && j < jhi[0], v1 = j >= jlo[1] && j < jhi[1];
-            const bool all_valid = __all(v0 && v1);           // wave-uniform: no SAME-padding zero in this wave's rows
             const vec_t zero = {};
+            // Straight-line k-step loop (no branch: the SAME-padding select is unconditional), with
+            // the fragments of k-step s+1 fetched before the MFMAs of k-step s are issued.
+            vec_t fa0[2], fa1[2], fb0[2], fb1[2];
+            fa0[0] = *reinterpret_cast<const vec_t*>(ap);
+            fa1[0] = *reinterpret_cast<const vec_t*>(ap + 32 * CROWB);
+            fb0[0] = *reinterpret_cast<const vec_t*>(bp);
+            fb1[0] = *reinterpret_cast<const vec_t*>(bp + 32 * CROWB);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) {
-                vec_t av0 = *reinterpret_cast<const vec_t*>(ap + s4 * 32);
-                vec_t av1 = *reinterpret_cast<const vec_t*>(ap + 32 * CROWB + s4 * 32);
-                const vec_t bv0 = *reinterpret_cast<const vec_t*>(bp + s4 * 32);
-                const vec_t bv1 = *reinterpret_cast<const vec_t*>(bp + 32 * CROWB + s4 * 32);
-                if (!all_valid) {
-                    av0 = v0 ? av0 : zero;
-                    av1 = v1 ? av1 : zero;
+                const int cur = s4 & 1, nxt = cur ^ 1;
+                if (s4 < 3) {
+                    fa0[nxt] = *reinterpret_cast<const vec_t*>(ap + (s4 + 1) * 32);
+                    fa1[nxt] = *reinterpret_cast<const vec_t*>(ap + 32 * CROWB + (s4 + 1) * 32);
+                    fb0[nxt] = *reinterpret_cast<const vec_t*>(bp + (s4 + 1) * 32);
+                    fb1[nxt] = *reinterpret_cast<const vec_t*>(bp + 32 * CROWB + (s4 + 1) * 32);
                 }
+                const vec_t av0 = v0 ? fa0[cur] : zero;
+                const vec_t av1 = v1 ? fa1[cur] : zero;
+                const vec_t bv0 = fb0[cur], bv1 = fb1[cur];
                 if constexpr (sizeof(T) == 2) {
                     acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av0, bv0, acc[0][0], 0, 0, 0);
                     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av0, bv1, acc[0][1], 0, 0, 0);
@@ -599,6 +607,7 @@ struct WGroup {
 struct WArgs {
     const void* XT;     // [Cin, ldxt], pointer at frame 0 (margin before it)
     int32_t ldxt, ldyt, Cin, M, T, n_groups;
+    int32_t splits;     // frame range split over gridDim.z; > 1 => float atomics into a zeroed dW
     WGroup g[VC_GEMM_MAX_GROUPS];
 };
 
@@ -618,7 +627,11 @@ wgrad_kernel(WArgs a) {
     const int rt = blockIdx.x / ntn, nt = blockIdx.x - rt * ntn;
     const int r0 = rt * BM, n0 = nt * BN;
     const int Tn = a.T, M = a.M;
-    const int nk = (M + BK - 1) / BK;
+    const int nk_all = (M + BK - 1) / BK;
+    const int per = (nk_all + a.splits - 1) / a.splits;
+    const int k_lo = (int)blockIdx.z * per, k_hi = min(nk_all, k_lo + per);
+    const int nk = k_hi - k_lo;
+    if (nk <= 0) return;
     const float* XT = reinterpret_cast<const float*>(a.XT);
     const float* YT = reinterpret_cast<const float*>(grp.dYT);
 
@@ -640,7 +653,7 @@ wgrad_kernel(WArgs a) {
         b_base[p] = YT + (size_t)min(n, grp.N - 1) * a.ldyt + sc * 4;
     }
     f32x4 ra[4], rb[4];
-    int g_m = 0;                                          // first frame of the next slab to load
+    int g_m = k_lo * BK;                                  // first frame of the next slab to load
     int st_m = 0;
     auto gload = [&]() {
         // a tail slab (M % 32 != 0) reads up to 31 frames past M: inside the operands' zero margin
@@ -701,7 +714,10 @@ wgrad_kernel(WArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int gr = r0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (gr < R) dW[(size_t)gr * grp.ldw + gn] = acc[mi][ni][r];
+                if (gr < R) {
+                    if (a.splits > 1) atomicAdd(dW + (size_t)gr * grp.ldw + gn, acc[mi][ni][r]);
+                    else dW[(size_t)gr * grp.ldw + gn] = acc[mi][ni][r];
+                }
             }
     }
 }
@@ -808,7 +824,17 @@ extern "C" int vc_conv_wgrad(const vc_wgrad_desc* d, void* stream) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes(2)));
         attr_done = true;
     }
-    hipLaunchKernelGGL(wgrad_kernel, dim3(max_tiles, d->n_groups), dim3(GEMM_THREADS), lds_bytes(2),
+    // Small grids (dense / highway / GRU filters) would run hundreds of K slabs serially on a few
+    // CUs: split the frame range over gridDim.z until ~2 blocks per CU exist.  The caller zeroes dW
+    // when it passes splits_allowed (atomic accumulation); the summation order is then not fixed.
+    int splits = 1;
+    if (d->splits_allowed) {
+        const long blocks = (long)max_tiles * d->n_groups;
+        const int nk_all = (d->M + 31) / 32;
+        while (blocks * splits < 512 && splits * 2 <= 32 && nk_all / (splits * 2) >= 8) splits *= 2;
+    }
+    wa.splits = splits;
+    hipLaunchKernelGGL(wgrad_kernel, dim3(max_tiles, d->n_groups, splits), dim3(GEMM_THREADS), lds_bytes(2),
                        static_cast<hipStream_t>(stream), wa);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;

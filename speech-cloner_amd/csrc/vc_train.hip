@@ -434,6 +434,196 @@ gru_bwd_kernel(GruBwdArgs a) {
     }
 }
 
+
+// ---------------------------------------------------------------------------- GRU (training), S sequences per WG
+// The one-sequence kernels above re-read the whole recurrent matrix (3H^2 floats = 786 KB at H = 256)
+// from L2 every step.  Here a workgroup advances S windows of one direction, so every weight
+// load feeds S FMAs; h lives in LDS as [S][H] and is read back as float4 broadcasts.
+constexpr int GS = 4;
+
+__global__ void __launch_bounds__(512)
+gru_train_fwd_ms_kernel(GruTrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int H = a.H, H3 = 3 * H, NT = blockDim.x, tid = threadIdx.x;
+    float* h = reinterpret_cast<float*>(smem);      // [GS][H]
+    float* rhs = h + GS * H;                        // [GS][H]
+    float* us = rhs + GS * H;                       // [GS][H]
+    const int seq0 = blockIdx.x * GS, dir = blockIdx.y;
+    const float* W = a.Wh[dir];
+    const size_t MT = (size_t)a.n_seq * a.T;
+    float* gates = a.gates + (size_t)dir * MT * H3;
+    float* rhg = a.rh + (size_t)dir * MT * H;
+    for (int i = tid; i < GS * H; i += NT) h[i] = 0.0f;
+    __syncthreads();
+    const size_t xrow = 6 * (size_t)H;
+    int t = dir ? a.T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    int sq[GS];
+#pragma unroll
+    for (int s = 0; s < GS; ++s) sq[s] = min(seq0 + s, a.n_seq - 1);
+    for (int step = 0; step < a.T; ++step, t += dt) {
+        for (int col = tid; col < 2 * H; col += NT) {
+            float acc[GS];
+#pragma unroll
+            for (int s = 0; s < GS; ++s) acc[s] = a.xproj[((size_t)sq[s] * a.T + t) * xrow + (size_t)dir * H3 + col];
+            const float* w = W + col;
+            for (int k = 0; k < H; k += 4) {
+                const float w0 = w[(size_t)k * H3], w1 = w[(size_t)(k + 1) * H3], w2 = w[(size_t)(k + 2) * H3], w3 = w[(size_t)(k + 3) * H3];
+#pragma unroll
+                for (int s = 0; s < GS; ++s) {
+                    const f4 hv = *reinterpret_cast<const f4*>(h + s * H + k);
+                    acc[s] = fmaf(hv[0], w0, acc[s]); acc[s] = fmaf(hv[1], w1, acc[s]);
+                    acc[s] = fmaf(hv[2], w2, acc[s]); acc[s] = fmaf(hv[3], w3, acc[s]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < GS; ++s) {
+                const float g = sigmoidf_(acc[s]);
+                const size_t row = (size_t)sq[s] * a.T + t;
+                if (seq0 + s < a.n_seq) gates[row * H3 + col] = g;
+                if (col < H) {
+                    const float v = g * h[s * H + col];
+                    rhs[s * H + col] = v;
+                    if (seq0 + s < a.n_seq) rhg[row * H + col] = v;
+                } else {
+                    us[s * H + col - H] = g;
+                }
+            }
+        }
+        __syncthreads();
+        float hn[GS];
+        for (int col = tid; col < H; col += NT) {
+            float acc[GS];
+#pragma unroll
+            for (int s = 0; s < GS; ++s) acc[s] = a.xproj[((size_t)sq[s] * a.T + t) * xrow + (size_t)dir * H3 + 2 * H + col];
+            const float* w = W + 2 * H + col;
+            for (int k = 0; k < H; k += 4) {
+                const float w0 = w[(size_t)k * H3], w1 = w[(size_t)(k + 1) * H3], w2 = w[(size_t)(k + 2) * H3], w3 = w[(size_t)(k + 3) * H3];
+#pragma unroll
+                for (int s = 0; s < GS; ++s) {
+                    const f4 rv = *reinterpret_cast<const f4*>(rhs + s * H + k);
+                    acc[s] = fmaf(rv[0], w0, acc[s]); acc[s] = fmaf(rv[1], w1, acc[s]);
+                    acc[s] = fmaf(rv[2], w2, acc[s]); acc[s] = fmaf(rv[3], w3, acc[s]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < GS; ++s) {
+                const float c = tanhf(acc[s]);
+                const float u = us[s * H + col];
+                hn[s] = u * h[s * H + col] + (1.0f - u) * c;
+                if (seq0 + s < a.n_seq) {
+                    const size_t row = (size_t)sq[s] * a.T + t;
+                    gates[row * H3 + 2 * H + col] = c;
+                    a.out[row * 2 * H + (size_t)dir * H + col] = hn[s];
+                }
+            }
+        }
+        __syncthreads();
+        // H <= NT here (one candidate column per thread at most), so hn[] of this thread is its column's
+        for (int col = tid; col < H; col += NT)
+#pragma unroll
+            for (int s = 0; s < GS; ++s) h[s * H + col] = hn[s];
+        __syncthreads();
+    }
+}
+
+struct GruBwdMsArgs {
+    GruBwdArgs b;
+    const float* WhT[2];     // [3H, H] transposed recurrent weights (coalesced matvecs with W^T)
+};
+
+__global__ void __launch_bounds__(512)
+gru_bwd_ms_kernel(GruBwdMsArgs aa) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const GruBwdArgs& a = aa.b;
+    const int H = a.H, H3 = 3 * H, NT = blockDim.x, tid = threadIdx.x;
+    float* dh = reinterpret_cast<float*>(smem);     // [GS][H]
+    float* dcp = dh + GS * H;                       // [GS][H]
+    float* dgp = dcp + GS * H;                      // [GS][2H]
+    float* drh = dgp + GS * 2 * H;                  // [GS][H]
+    const int seq0 = blockIdx.x * GS, dir = blockIdx.y;
+    const float* WT = aa.WhT[dir];                  // WT[col][k] = W[k][col]
+    const size_t MT = (size_t)a.n_seq * a.T;
+    const float* gates = a.gates + (size_t)dir * MT * H3;
+    for (int i = tid; i < GS * H; i += NT) dh[i] = 0.0f;
+    __syncthreads();
+    int sq[GS];
+#pragma unroll
+    for (int s = 0; s < GS; ++s) sq[s] = min(seq0 + s, a.n_seq - 1);
+    int t = dir ? 0 : a.T - 1;
+    const int dtb = dir ? 1 : -1;
+    for (int step = 0; step < a.T; ++step, t += dtb) {
+        const bool first = (step == a.T - 1);
+        for (int i = tid; i < GS * H; i += NT) {
+            const int s = i / H, j = i - s * H;
+            const size_t row = (size_t)sq[s] * a.T + t;
+            const float g = dh[i] + a.dout[row * 2 * H + (size_t)dir * H + j];
+            const float u = gates[row * H3 + H + j], c = gates[row * H3 + 2 * H + j];
+            const float hp = first ? 0.0f : a.out[(row + dtb) * 2 * H + (size_t)dir * H + j];
+            dcp[i] = g * (1.0f - u) * (1.0f - c * c);
+            dgp[s * 2 * H + H + j] = g * (hp - c) * u * (1.0f - u);
+            dh[i] = g * u;
+        }
+        __syncthreads();
+        // d(rh)[k] = sum_j W[k][2H + j] dc_pre[j] = sum_j WT[2H + j][k] dc_pre[j]
+        for (int k = tid; k < H; k += NT) {
+            float acc[GS];
+#pragma unroll
+            for (int s = 0; s < GS; ++s) acc[s] = 0.0f;
+            const float* w = WT + (size_t)2 * H * H + k;
+            for (int j = 0; j < H; j += 4) {
+                const float w0 = w[(size_t)j * H], w1 = w[(size_t)(j + 1) * H], w2 = w[(size_t)(j + 2) * H], w3 = w[(size_t)(j + 3) * H];
+#pragma unroll
+                for (int s = 0; s < GS; ++s) {
+                    const f4 v = *reinterpret_cast<const f4*>(dcp + s * H + j);
+                    acc[s] = fmaf(w0, v[0], acc[s]); acc[s] = fmaf(w1, v[1], acc[s]);
+                    acc[s] = fmaf(w2, v[2], acc[s]); acc[s] = fmaf(w3, v[3], acc[s]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < GS; ++s) drh[s * H + k] = acc[s];
+        }
+        __syncthreads();
+        for (int i = tid; i < GS * H; i += NT) {
+            const int s = i / H, j = i - s * H;
+            const size_t row = (size_t)sq[s] * a.T + t;
+            const float r = gates[row * H3 + j];
+            const float hp = first ? 0.0f : a.out[(row + dtb) * 2 * H + (size_t)dir * H + j];
+            dgp[s * 2 * H + j] = drh[i] * hp * r * (1.0f - r);
+            dh[i] += drh[i] * r;
+        }
+        __syncthreads();
+        // dh_prev[k] += sum_{j < 2H} W[k][j] dg_pre[j] = sum_j WT[j][k] dg_pre[j]
+        for (int k = tid; k < H; k += NT) {
+            float acc[GS];
+#pragma unroll
+            for (int s = 0; s < GS; ++s) acc[s] = 0.0f;
+            const float* w = WT + k;
+            for (int j = 0; j < 2 * H; j += 4) {
+                const float w0 = w[(size_t)j * H], w1 = w[(size_t)(j + 1) * H], w2 = w[(size_t)(j + 2) * H], w3 = w[(size_t)(j + 3) * H];
+#pragma unroll
+                for (int s = 0; s < GS; ++s) {
+                    const f4 v = *reinterpret_cast<const f4*>(dgp + s * 2 * H + j);
+                    acc[s] = fmaf(w0, v[0], acc[s]); acc[s] = fmaf(w1, v[1], acc[s]);
+                    acc[s] = fmaf(w2, v[2], acc[s]); acc[s] = fmaf(w3, v[3], acc[s]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < GS; ++s) dh[s * H + k] += acc[s];
+        }
+        for (int i = tid; i < GS * 3 * H; i += NT) {
+            const int s = i / H3, j = i - s * H3;
+            if (seq0 + s < a.n_seq) {
+                const size_t row = (size_t)sq[s] * a.T + t;
+                a.dpre[row * 6 * (size_t)H + (size_t)dir * H3 + j] = j < 2 * H ? dgp[s * 2 * H + j] : dcp[s * H + j - 2 * H];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 inline int nblocks(size_t n) {
     size_t b = (n + TB - 1) / TB;
     return (int)(b < 8192 ? (b ? b : 1) : 8192);
@@ -566,20 +756,32 @@ int vc_gru_train_forward(const float* d_xproj, const float* d_Wh_fw, const float
     a.xproj = d_xproj; a.Wh[0] = d_Wh_fw; a.Wh[1] = d_Wh_bw; a.out = d_out; a.gates = d_gates; a.rh = d_rh;
     a.n_seq = n_seq; a.T = T; a.H = H;
     const int nt = H >= 128 ? 512 : 256;
-    hipLaunchKernelGGL(gru_train_fwd_kernel, dim3(n_seq, 2), dim3(nt), 3 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
+    if (H % 4 == 0 && H <= nt) {                          // multi-sequence kernel (GS windows per workgroup)
+        const size_t lds = 3 * (size_t)GS * H * 4;
+        hipLaunchKernelGGL(gru_train_fwd_ms_kernel, dim3((n_seq + GS - 1) / GS, 2), dim3(nt), lds, static_cast<hipStream_t>(stream), a);
+    } else {
+        hipLaunchKernelGGL(gru_train_fwd_kernel, dim3(n_seq, 2), dim3(nt), 3 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
+    }
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }
 
 int vc_gru_backward(const float* d_dout, const float* d_out, const float* d_gates, const float* d_Wh_fw,
-                    const float* d_Wh_bw, int32_t n_seq, int32_t T, int32_t H, float* d_dpre, void* stream) {
+                    const float* d_Wh_bw, const float* d_WhT_fw, const float* d_WhT_bw, int32_t n_seq, int32_t T,
+                    int32_t H, float* d_dpre, void* stream) {
     VC_REQUIRE(d_dout && d_out && d_gates && d_Wh_fw && d_Wh_bw && d_dpre, "NULL argument");
     VC_REQUIRE(n_seq > 0 && T > 0 && H > 0 && H <= 1024, "bad shape");
     GruBwdArgs a;
     a.dout = d_dout; a.out = d_out; a.gates = d_gates; a.Wh[0] = d_Wh_fw; a.Wh[1] = d_Wh_bw; a.dpre = d_dpre;
     a.n_seq = n_seq; a.T = T; a.H = H;
     const int nt = H >= 128 ? 512 : 256;
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3(n_seq, 2), dim3(nt), 5 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
+    if (d_WhT_fw && d_WhT_bw && H % 4 == 0) {             // multi-sequence kernel with transposed weights
+        GruBwdMsArgs aa;
+        aa.b = a; aa.WhT[0] = d_WhT_fw; aa.WhT[1] = d_WhT_bw;
+        hipLaunchKernelGGL(gru_bwd_ms_kernel, dim3((n_seq + GS - 1) / GS, 2), dim3(nt), 5 * (size_t)GS * H * 4,
+                           static_cast<hipStream_t>(stream), aa);
+    } else
+        hipLaunchKernelGGL(gru_bwd_kernel, dim3(n_seq, 2), dim3(nt), 5 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }

@@ -60,6 +60,7 @@ class _Ops:
         d = _vc.WgradDesc()
         d.d_XT = XT.data_ptr() + MARGIN * 4
         d.ldxt, d.ldyt, d.Cin, d.M, d.T, d.margin, d.n_groups = ldxt, ldyt, Cin, M, T, MARGIN, len(groups)
+        d.splits_allowed = 1                      # the gradient arena is zeroed at the start of every step
         for i, (roff, N, taps, shift0, dW, ldw) in enumerate(groups):
             g = d.groups[i]
             g.d_dYT = dYT.data_ptr() + (roff * ldyt + MARGIN) * 4
@@ -278,7 +279,9 @@ class DecoderTrainer:
         gs = s + '/CBHG/gru'
         wh_fw, wh_bw = sv['wh']
         dpre = torch.empty((M, 6 * H), dtype=torch.float32, device=dev)
-        _vc.check(_lib().vc_gru_backward(_p(dG), _p(sv['G']), _p(sv['gates']), _p(wh_fw), _p(wh_bw), N_, T_, H, _p(dpre), _st()))
+        whT_fw, whT_bw = wh_fw.t().contiguous(), wh_bw.t().contiguous()
+        _vc.check(_lib().vc_gru_backward(_p(dG), _p(sv['G']), _p(sv['gates']), _p(wh_fw), _p(wh_bw), _p(whT_fw), _p(whT_bw),
+                                         N_, T_, H, _p(dpre), _st()))
         dbx = torch.empty(6 * H, dtype=torch.float32, device=dev)
         _Ops.col_sum(dpre, M, 6 * H, 6 * H, dbx)
         dpT, ldp = _Ops.transpose(dpre, M, 6 * H, 6 * H, T_)
@@ -426,6 +429,7 @@ class DecoderTrainer:
             ppg[:, :, :n_in] = x
         self.last_ppg = ppg
         M = ppg.shape[0] * ppg.shape[1]
+        _vc.check(_lib().vc_fill(_p(self.grad), 0.0, self.total, _st()))     # wgrad accumulates with atomics
         sd1, sd2 = c['steps_v'][0], c['steps_v'][1]
         seed = self.seed + 1000 * self.step_count
         with modules.variable_store(self.store):
