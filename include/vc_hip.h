@@ -282,6 +282,12 @@ int vc_fill(float* d_p, float value, size_t n, void* stream);
  * left untouched).  d_workspace: 256 floats; d_loss: 1 float on the device (no host sync). */
 int vc_mse_loss(const float* d_y, const float* d_t, size_t n, float weight, float* d_dY, int32_t C, int32_t ld_dy,
                 float* d_loss, float* d_workspace, void* stream);
+/* Encoder loss and metrics (/root/reference/encoder.py:134-150): out3 = [mean softmax cross-entropy
+ * with float labels, accuracy of argmax(logits) vs argmax(target), mean squared error of the
+ * posteriors]; optional d_dlogits [M, ldd] = (softmax * sum(target) - target) / M.
+ * d_workspace: 3 * M floats; results stay on the device. */
+int vc_softmax_ce(const float* d_logits, const float* d_target, int32_t M, int32_t C, int32_t ldl, float* d_dlogits,
+                  int32_t ldd, float* d_out3, float* d_workspace, void* stream);
 /* tf.train.AdamOptimizer update on flat buffers (decoder.py:236-246): g is first multiplied by
  * grad_scale (1/world for data-parallel averaging), lr_t = lr*sqrt(1-b2^t)/(1-b1^t) from the host,
  * p -= lr_t * m / (sqrt(v) + epsilon). */

@@ -174,14 +174,16 @@ def cbhg(x, w, scope, K, n_highway, is_training=False, stats_out=None, taps=None
 
 
 # --------------------------------------------------------------------------- models
-def encoder_forward(x, w, cfg, scope=None, taps=None):
-    """encoder.py:78-123 in inference mode.  Returns (y_logits, y_pred, y_pred_class, CBHG_out)."""
+def encoder_forward(x, w, cfg, scope=None, taps=None, is_training=False, masks=None, stats_out=None):
+    """encoder.py:78-123.  Inference mode by default; ``is_training`` switches batch norm to batch
+    statistics and ``masks`` = (mask1, mask2) are the prenet dropout keep-masks.
+    Returns (y_logits, y_pred, y_pred_class, CBHG_out)."""
     scope = scope or cfg.get('model_name', 'encoder')
-    pre = prenet(x, w, scope + '/prenet', cfg['dropout_rate'], None)
+    pre = prenet(x, w, scope + '/prenet', cfg['dropout_rate'], masks)
     if taps is not None:
         taps['prenet'] = pre
     out = cbhg(pre, w, scope + '/CBHG', cfg['num_conv_banks'], cfg['num_highwaynet_blocks'],
-               taps=taps)
+               is_training, stats_out, taps=taps)
     logits = dense(out, w, scope + '/y_logits')
     pred = torch.softmax(logits, dim=-1)
     cls = torch.argmax(logits, dim=-1).to(torch.int32)
@@ -230,6 +232,14 @@ def decoder_loss(y_mel, y_stft, t_mel, t_stft, cfg):
 def encoder_loss(logits, target):
     """encoder.py:134-137: mean softmax cross-entropy with (one-hot) float labels."""
     return -(target * torch.log_softmax(logits, dim=-1)).sum(-1).mean()
+
+
+def encoder_metrics(logits, target):
+    """encoder.py:143-150: accuracy of argmax(pred) vs argmax(target), mse of the posteriors."""
+    pred = torch.softmax(logits, dim=-1)
+    acc = (pred.argmax(-1) == target.argmax(-1)).double().mean()
+    mse = ((pred - target) ** 2).mean()
+    return acc, mse
 
 
 def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):

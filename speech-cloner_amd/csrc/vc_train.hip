@@ -624,6 +624,78 @@ gru_bwd_ms_kernel(GruBwdMsArgs aa) {
     }
 }
 
+
+// ---------------------------------------------------------------------------- encoder loss / metrics
+// tf.nn.softmax_cross_entropy_with_logits_v2 + reduce_mean (/root/reference/encoder.py:134-137),
+// accuracy of argmax(pred) vs argmax(target) and mean squared error of the posteriors
+// (encoder.py:143-150).  One wave per row; per-row values go to a workspace and are summed by
+// one block in a fixed order (deterministic).  dlogits = (p * sum(t) - t) / M.
+__global__ void __launch_bounds__(256)
+softmax_ce_rows_kernel(const float* logits, const float* target, int M, int C, int ldl, float* dlogits, int ldd,
+                       float* rowvals) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* x = logits + (size_t)row * ldl;
+    const float* t = target + (size_t)row * C;
+    float mx = -3.402823466e38f, tmx = -3.402823466e38f;
+    int mi = 0x7fffffff, tmi = 0x7fffffff;
+    for (int c = lane; c < C; c += 64) {
+        const float v = x[c], tv = t[c];
+        if (v > mx) { mx = v; mi = c; }
+        if (tv > tmx) { tmx = tv; tmi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(mi, o, 64);
+        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+        const float tv = __shfl_xor(tmx, o, 64); const int ti = __shfl_xor(tmi, o, 64);
+        if (tv > tmx || (tv == tmx && ti < tmi)) { tmx = tv; tmi = ti; }
+    }
+    float se = 0.0f, st = 0.0f, stx = 0.0f;
+    for (int c = lane; c < C; c += 64) {
+        se += expf(x[c] - mx);
+        st += t[c];
+        stx = fmaf(t[c], x[c] - mx, stx);
+    }
+    se = vc::wave_sum(se); st = vc::wave_sum(st); stx = vc::wave_sum(stx);
+    const float lse = logf(se);
+    const float inv = 1.0f / se, invM = 1.0f / (float)M;
+    float sq = 0.0f;
+    for (int c = lane; c < C; c += 64) {
+        const float pc = expf(x[c] - mx) * inv;
+        const float d = pc - t[c];
+        sq = fmaf(d, d, sq);
+        if (dlogits) dlogits[(size_t)row * ldd + c] = (pc * st - t[c]) * invM;
+    }
+    sq = vc::wave_sum(sq);
+    if (lane == 0) {
+        rowvals[row] = st * lse - stx;                       // -sum t log p
+        rowvals[(size_t)M + row] = (mi == tmi) ? 1.0f : 0.0f;
+        rowvals[2 * (size_t)M + row] = sq;
+    }
+}
+__global__ void __launch_bounds__(256)
+reduce3_kernel(const float* rowvals, int M, int C, float* out) {
+    __shared__ double red[3][256];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int r = threadIdx.x; r < M; r += 256) {
+        a0 += (double)rowvals[r]; a1 += (double)rowvals[(size_t)M + r]; a2 += (double)rowvals[2 * (size_t)M + r];
+    }
+    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o)
+            for (int q = 0; q < 3; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = (float)(red[0][0] / M);                     // loss
+        out[1] = (float)(red[1][0] / M);                     // accuracy
+        out[2] = (float)(red[2][0] / ((double)M * C));       // mse
+    }
+}
+
 inline int nblocks(size_t n) {
     size_t b = (n + TB - 1) / TB;
     return (int)(b < 8192 ? (b ? b : 1) : 8192);
@@ -782,6 +854,18 @@ int vc_gru_backward(const float* d_dout, const float* d_out, const float* d_gate
                            static_cast<hipStream_t>(stream), aa);
     } else
         hipLaunchKernelGGL(gru_bwd_kernel, dim3(n_seq, 2), dim3(nt), 5 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_softmax_ce(const float* d_logits, const float* d_target, int32_t M, int32_t C, int32_t ldl, float* d_dlogits,
+                  int32_t ldd, float* d_out3, float* d_workspace, void* stream) {
+    VC_REQUIRE(d_logits && d_target && d_out3 && d_workspace, "NULL argument");
+    VC_REQUIRE(M > 0 && C > 0 && ldl >= C && (d_dlogits == nullptr || ldd >= C), "bad shape");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(softmax_ce_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, st, d_logits, d_target, M, C, ldl, d_dlogits, ldd,
+                       d_workspace);
+    hipLaunchKernelGGL(reduce3_kernel, dim3(1), dim3(256), 0, st, d_workspace, M, C, d_out3);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }

@@ -160,9 +160,7 @@ class decoder_specs:
         d.update(self.opt_state)
         tr = getattr(self, '_trainer', None)
         if tr is not None:                            # Adam slots under TF's names (dec_opt/<var>/Adam[_1])
-            for n, (m, v) in tr.adam_slots().items():
-                d['dec_opt/' + n + '/Adam'] = m.cpu().numpy()
-                d['dec_opt/' + n + '/Adam_1'] = v.cpu().numpy()
+            d.update(tr.slot_dict())
         return d
 
     def save(self, save_path=None, i_checkpoint=None, verbose=True):

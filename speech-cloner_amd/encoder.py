@@ -11,8 +11,8 @@ Differences a caller can see (documented, deliberate):
   * ``inputs``, ``y_pred`` ... are light-weight handles (there is no graph); ``run(var, feed_dict)``
     evaluates the handles this class defines.
   * optional config key ``compute_dtype`` ('float32' default | 'bfloat16').
-  * the encoder's own training loop (``train``/``exec_train_step``, encoder.py:256-356) is a
-    "next" row of SURVEY.md section 8f and raises NotImplementedError for now.
+  * training (``exec_train_step`` / ``exec_calc_metrics`` / ``train``, encoder.py:256-356) runs in
+    float32 through training.EncoderTrainer; TensorBoard summaries are not written.
 """
 import os
 import sys
@@ -115,7 +115,8 @@ class encoder_spec_phn:
         import torch
         c = self.cfg_d
         if c['is_training']:
-            raise NotImplementedError(' - ERROR, encoder training mode is not built yet (SURVEY.md section 8f)')
+            raise Exception(' - ERROR, forward() is the inference graph; a model built with is_training=True '
+                            'is evaluated through exec_train_step / exec_calc_metrics')
         st = self.store
         with modules.variable_store(st), modules.variable_scope(self._scope):
             xin = modules.convert(x, st.dtype)
@@ -134,8 +135,11 @@ class encoder_spec_phn:
 
     # --------------------------------------------------------------------------- checkpoints
     def _all_variables(self):
-        d = self.store.to_numpy()
+        d = {n: v for n, v in self.store.to_numpy().items() if n.startswith(self._scope + '/')}
         d.update(self.opt_state)
+        tr = getattr(self, '_trainer', None)
+        if tr is not None:
+            d.update(tr.slot_dict())                   # opt/<var>/Adam[_1], opt/beta{1,2}_power
         return d
 
     def save(self, save_path=None, i_checkpoint=None, verbose=True):
@@ -160,8 +164,13 @@ class encoder_spec_phn:
             else:
                 save_path = '{}/{}-{}'.format(self.cfg_d['model_path'], self.cfg_d['model_name'], int(i_checkpoint))
         try:
-            names = set(n for n in self.store.vars if n.startswith(self._scope + '/')) | set(self.opt_state)
+            names = None if self.cfg_d['is_training'] else \
+                set(n for n in self.store.vars if n.startswith(self._scope + '/')) | set(self.opt_state)
             w = tf_bundle.read_bundle(save_path, verify_crc=True, names=names)
+            if self.cfg_d['is_training']:              # Adam slots are picked up when the trainer is created
+                self._restored_ckpt = w
+                if getattr(self, '_trainer', None) is not None:
+                    self._trainer.load_slots(w)
             self.store.load_dict({k: v for k, v in w.items() if k in self.store.vars}, strict=False)
             missing = [n for n in self.store.vars if n.startswith(self._scope + '/') and n not in w]
             if missing:
@@ -217,13 +226,108 @@ class encoder_spec_phn:
             print('acc[{:4d}] = {:5.03f}'.format(int(n_t), acc))
         return acc, n_t
 
-    def exec_train_step(self, inputs, target):
-        raise NotImplementedError(' - ERROR, encoder training is a "next" row (SURVEY.md section 8f)')
-
-    def exec_calc_metrics(self, inputs, target, summary_mode='validation'):
-        raise NotImplementedError(' - ERROR, encoder training is a "next" row (SURVEY.md section 8f)')
-
-    def train(self):
+    # --------------------------------------------------------------------------- training
+    def _get_trainer(self):
         if not self.cfg_d['is_training']:
             raise Exception('Model is not in training model')
-        raise NotImplementedError(' - ERROR, encoder training is a "next" row (SURVEY.md section 8f)')
+        if getattr(self, '_trainer', None) is None:
+            import training
+            self._trainer = training.EncoderTrainer(self)
+            if getattr(self, '_restored_ckpt', None) is not None:      # resume Adam state like tf.train.Saver
+                self._trainer.load_slots(self._restored_ckpt)
+                self._restored_ckpt = None
+        return self._trainer
+
+    def _target_to_device(self, target):
+        import torch
+        if not torch.is_tensor(target):
+            target = torch.from_numpy(np.ascontiguousarray(target, dtype=np.float32))
+        target = target.to(self.store.device, dtype=torch.float32).contiguous()
+        T, n_out = self.cfg_d['input_shape'][0], self.cfg_d['n_output']
+        if target.dim() != 3 or tuple(target.shape[1:]) != (T, n_out):
+            raise ValueError(' - ERROR, target must be [N, {}, {}], got {}'.format(T, n_out, tuple(target.shape)))
+        return target
+
+    def exec_train_step(self, inputs, target):
+        """encoder.py:256-270: forward (dropout, batch statistics) + softmax cross-entropy + backward +
+        Adam.  Returns (loss, acc, mse, global_step, train_step); train_step is None (a TF op)."""
+        import torch
+        tr = self._get_trainer()
+        out3 = tr.forward_backward(self._to_device(inputs), self._target_to_device(target), backward=True)
+        world = torch.distributed.get_world_size() if (torch.distributed.is_available() and
+                                                        torch.distributed.is_initialized()) else 1
+        global_step = tr.apply_gradients(world)
+        loss, acc, mse = (np.float32(v) for v in out3.cpu().numpy())
+        self.i_global_step = global_step
+        return (loss, acc, mse, np.int32(global_step), None)
+
+    def exec_calc_metrics(self, inputs, target, summary_mode='validation'):
+        """encoder.py:274-297 without the TensorBoard writers: (acc, mse, loss).  Like the reference's
+        graph, the forward runs in whatever mode the model was built in (training mode keeps dropout
+        and batch statistics active and, with updates_collections=None, also moves the averages)."""
+        if summary_mode not in ('train', 'validation', 'test'):
+            raise Exception(' - ERROR, summary_mode={} not implemented'.format(summary_mode))
+        import torch
+        x, t = self._to_device(inputs), self._target_to_device(target)
+        if self.cfg_d['is_training']:
+            out3 = self._get_trainer().forward_backward(x, t, backward=False)
+        else:
+            import ctypes as C
+            import _vc
+            y = self.forward(x)['y_logits']
+            M, n_out = y.shape[0] * y.shape[1], y.shape[2]
+            out3 = torch.empty(3, dtype=torch.float32, device=y.device)
+            ws = torch.empty(3 * M, dtype=torch.float32, device=y.device)
+            _vc.check(_vc.lib().vc_softmax_ce(C.c_void_p(y.data_ptr()), C.c_void_p(t.data_ptr()), M, n_out, n_out, None, 0,
+                                              C.c_void_p(out3.data_ptr()), C.c_void_p(ws.data_ptr()), _vc.current_stream()))
+        loss, acc, mse = (np.float32(v) for v in out3.cpu().numpy())
+        return acc, mse, loss
+
+    def _lr_decay(self):
+        """encoder.py:183: lr = lr_start / (1 + decay * epoch)."""
+        o = self.opt_state
+        o['opt/learning_rate'] = np.float32(float(o['opt/learning_rate_start']) /
+                                            (1.0 + float(o['opt/learning_rate_decay']) * float(o['opt/epoch'])))
+        return o['opt/learning_rate']
+
+    def train(self):
+        """encoder.py:300-356 (same prints and control flow; needs a dataset object providing
+        get_ds_filter / window_sampler, which this package does not ship)."""
+        if not self.cfg_d['is_training']:
+            raise Exception('Model is not in training model')
+        self.cfg_d['n_samples_trn'] = self.ds.get_ds_filter(self.cfg_d['ds_trn_filter_d']).sum()
+        self.cfg_d['n_steps_epoch_trn'] = self.cfg_d['n_samples_trn'] // self.cfg_d['batch_size']
+        self.sampler_trn = self.ds.window_sampler(batch_size=self.cfg_d['batch_size'], n_epochs=99999999,
+                                                  randomize_samples=self.cfg_d['randomize_samples'],
+                                                  ds_filter_d=self.cfg_d['ds_trn_filter_d'])
+        self.sampler_val = self.ds.window_sampler(batch_size=self.cfg_d['batch_size'], n_epochs=99999999,
+                                                  randomize_samples=self.cfg_d['randomize_samples'],
+                                                  ds_filter_d=self.cfg_d['ds_val_filter_d'])
+        self.iter_val = iter(self.sampler_val)
+        print(' Starting Training ...')
+        print(' n_samples_trn:    ', self.cfg_d['n_samples_trn'])
+        print(' n_steps_epoch_trn:', self.cfg_d['n_steps_epoch_trn'])
+        print(' batch_size:       ', self.cfg_d['batch_size'])
+        print(' n_epochs:         ', self.cfg_d['n_epochs'])
+        input('Press --ENTER--')
+        self.i_epoch = int(self.opt_state['opt/epoch'])
+        self.lr = self._lr_decay()
+        for mfcc_trn, phn_v_trn in self.sampler_trn:
+            loss, acc, mse, global_step, train_step = self.exec_train_step(mfcc_trn, phn_v_trn)
+            print(' - i_epoch={}   global_step={}   loss_trn={:6.3f}  acc_trn={:6.3f}  mse_trn={:6.3f}'.format(
+                self.i_epoch, global_step, loss, acc, mse))
+            if (global_step / self.cfg_d['n_steps_epoch_trn']) % self.cfg_d['save_each_n_epochs'] == 0:
+                print(' Saving, epoch={} ...'.format(self.i_epoch))
+                self.save()
+                mfcc_val, phn_v_val = next(self.iter_val)
+                acc_val, mse_val, loss_val = self.exec_calc_metrics(mfcc_val, phn_v_val)
+                print(' - i_epoch={}   global_step={}   loss_val={:6.3f}  acc_val={:6.3f}   mse_val={:6.3f}'.format(
+                    self.i_epoch, int(global_step), loss_val, acc_val, mse_val))
+            if global_step % self.cfg_d['n_steps_epoch_trn'] == 0:
+                self.opt_state['opt/epoch'] = np.int32(int(self.opt_state['opt/epoch']) + 1)
+                self.i_epoch = int(self.opt_state['opt/epoch'])
+                self.lr = self._lr_decay()
+                if self.i_epoch >= self.cfg_d['n_epochs']:
+                    break
+        print(' End of Training !!!')
+        return None

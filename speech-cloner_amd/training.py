@@ -94,18 +94,22 @@ class _Ops:
         _vc.check(_lib().vc_col_sum(_p(X), M, Cn, ld, _p(out), int(accumulate), _p(ws), _st()))
 
 
-class DecoderTrainer:
-    """Owns the flat arenas and runs one training step for a ``decoder_specs`` object."""
+class StageTrainer:
+    """Flat parameter / gradient / Adam arenas for the variables under one model scope, plus the
+    train-mode forward and the backward of a prenet -> CBHG -> dense stage (shared by the decoder's
+    two stages and the encoder)."""
 
-    def __init__(self, decoder):
+    opt_scope = 'dec_opt'
+
+    def __init__(self, model):
         torch = _torch()
-        self.dec = decoder
-        self.store = decoder.store
+        self.dec = model
+        self.store = model.store
         if self.store.dtype != torch.float32:
             raise NotImplementedError(' - ERROR, training runs in float32 (compute_dtype must be float32)')
-        c = decoder.cfg_d
+        c = model.cfg_d
         self.cfg = c
-        scope = decoder._scope
+        scope = model._scope
         names = self.store.trainable_names(scope + '/')
         total = sum(self.store.vars[n].numel() for n in names)
         dev = self.store.device
@@ -125,11 +129,31 @@ class DecoderTrainer:
             off += k
         self.store.invalidate()
         self.total = total
-        self.step_count = int(decoder.opt_state['dec_opt/global_step'])
+        self.step_count = int(model.opt_state[self.opt_scope + '/global_step'])
         self.seed = int(c.get('dropout_seed', 1234))
         self.keep = 1.0 - float(c['dropout_rate'])
         self.loss_ws = torch.empty(256, dtype=torch.float32, device=dev)
         self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
+
+    def load_slots(self, ckpt):
+        """Resume Adam state from a checkpoint dict (TF slot names <opt>/<var>/Adam, /Adam_1)."""
+        torch = _torch()
+        for n, (m, v) in self.adam_slots().items():
+            km, kv = '{}/{}/Adam'.format(self.opt_scope, n), '{}/{}/Adam_1'.format(self.opt_scope, n)
+            if km in ckpt and kv in ckpt:
+                m.copy_(torch.from_numpy(np.ascontiguousarray(ckpt[km], dtype=np.float32)))
+                v.copy_(torch.from_numpy(np.ascontiguousarray(ckpt[kv], dtype=np.float32)))
+
+    def slot_dict(self):
+        """Adam slots + beta powers under TF's names, for save()."""
+        c = self.cfg
+        d = {}
+        for n, (m, v) in self.adam_slots().items():
+            d['{}/{}/Adam'.format(self.opt_scope, n)] = m.cpu().numpy()
+            d['{}/{}/Adam_1'.format(self.opt_scope, n)] = v.cpu().numpy()
+        d[self.opt_scope + '/beta1_power'] = np.float32(float(c['beta1']) ** (self.step_count + 1))
+        d[self.opt_scope + '/beta2_power'] = np.float32(float(c['beta2']) ** (self.step_count + 1))
+        return d
 
     # ---------------------------------------------------------------- helpers
     def g(self, name):
@@ -413,6 +437,29 @@ class DecoderTrainer:
             dX0 = self._dgrad_dense(dZ1, E, E, W1p, M, T_)
         return dX0
 
+    def apply_gradients(self, world=1):
+        """All-reduce (data parallel), Adam, bookkeeping.  decoder.py:236-246 / encoder.py:171-181."""
+        torch = _torch()
+        c = self.cfg
+        if world > 1:
+            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+        self.step_count += 1
+        t = self.step_count
+        lr = float(self.dec.opt_state[self.opt_scope + '/learning_rate'])
+        b1, b2, eps = float(c['beta1']), float(c['beta2']), float(c['epsilon'])
+        lr_t = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
+        _vc.check(_lib().vc_adam_step(_p(self.flat), _p(self.grad), _p(self.m), _p(self.v), self.total, lr_t, b1, b2, eps,
+                                      1.0 / world, _st()))
+        self.store.invalidate()                   # kernel-layout copies are stale now
+        self.dec.opt_state[self.opt_scope + '/global_step'] = np.int32(t)
+        return t
+
+
+class DecoderTrainer(StageTrainer):
+    """One training step of ``decoder_specs`` (decoder.py:185-263, 327-345)."""
+
+    opt_scope = 'dec_opt'
+
     # ---------------------------------------------------------------- whole step
     def forward_backward(self, x, target_mel, target_stft):
         """Forward + backward of one batch.  Returns the device tensor [mel_loss, stft_loss]."""
@@ -461,19 +508,32 @@ class DecoderTrainer:
             self._stage_backward(s1, sv1, dY1, need_dx=False)
         return self.losses
 
-    def apply_gradients(self, world=1):
-        """All-reduce (data parallel), Adam, bookkeeping.  decoder.py:236-246."""
+
+class EncoderTrainer(StageTrainer):
+    """One training step of ``encoder_spec_phn`` (encoder.py:134-194, 256-270): train-mode forward of
+    the single prenet -> CBHG -> dense(n_output) stage, softmax cross-entropy with float labels,
+    accuracy / mse metrics, backward, Adam."""
+
+    opt_scope = 'opt'
+
+    def forward_backward(self, x, target, backward=True):
+        """Returns the device tensor [loss, acc, mse]."""
         torch = _torch()
-        c = self.cfg
-        if world > 1:
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
-        self.step_count += 1
-        t = self.step_count
-        lr = float(self.dec.opt_state['dec_opt/learning_rate'])
-        b1, b2, eps = float(c['beta1']), float(c['beta2']), float(c['epsilon'])
-        lr_t = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
-        _vc.check(_lib().vc_adam_step(_p(self.flat), _p(self.grad), _p(self.m), _p(self.v), self.total, lr_t, b1, b2, eps,
-                                      1.0 / world, _st()))
-        self.store.invalidate()                   # kernel-layout copies are stale now
-        self.dec.opt_state['dec_opt/global_step'] = np.int32(t)
-        return t
+        enc, c = self.dec, self.cfg
+        N_, T_, Cx = x.shape
+        M = N_ * T_
+        n_out = c['n_output']
+        seed = self.seed + 1000 * self.step_count
+        if backward:
+            _vc.check(_lib().vc_fill(_p(self.grad), 0.0, self.total, _st()))
+        with modules.variable_store(self.store):
+            y, sv = self._stage_forward(enc._scope, x, Cx, enc._embed_size, c['num_conv_banks'],
+                                        c['num_highwaynet_blocks'], n_out, seed)
+            self.y_logits = y
+            dY = torch.zeros_like(y) if backward else None
+            out3 = torch.empty(3, dtype=torch.float32, device=x.device)
+            ws = torch.empty(3 * M, dtype=torch.float32, device=x.device)
+            _vc.check(_lib().vc_softmax_ce(_p(y), _p(target), M, n_out, y.shape[1], _p(dY), y.shape[1], _p(out3), _p(ws), _st()))
+            if backward:
+                self._stage_backward(enc._scope, sv, dY, need_dx=False)
+        return out3
