@@ -305,6 +305,50 @@ int vc_gru_backward(const float* d_dout, const float* d_out, const float* d_gate
                     const float* d_Wh_bw, const float* d_WhT_fw, const float* d_WhT_bw, int32_t n_seq,
                     int32_t T, int32_t H, float* d_dpre, void* stream);
 
+/* ---- Griffin-Lim vocoder ---------------------------------------
+ * Replaces audio_lib.griffin_lim_alg / from_power_to_wav / calc_inv_preemphasis
+ * (/root/reference/audio_lib.py:249-274, 278-308, 31-47; called from test.py:146-168, 253-275,
+ * 346-362).  Spectrogram layout is frame-major: [batch, max_frames, 1 + n_fft/2] (the decoder's
+ * y_stft layout, i.e. the TRANSPOSE of the [bins, frames] array librosa works on). */
+typedef struct vc_vocoder_plan vc_vocoder_plan;
+
+/* Device tables (padded window, DFT twiddles).  n_fft <= 0 => n_fft = win_length
+ * (audio_lib.py:251-252).  h_window: host float64[win_length] or NULL for periodic hann (librosa's
+ * default, the only window the reference uses here).  n_fft == 400 takes the 25 x 16 split
+ * transform; other (even) sizes take a direct DFT. */
+int vc_vocoder_plan_create(int32_t win_length, int32_t hop_length, int32_t n_fft, const double* h_window,
+                           vc_vocoder_plan** out_plan);
+void vc_vocoder_plan_destroy(vc_vocoder_plan* plan);
+/* Samples librosa.istft returns for n_frames frames: hop_length * (n_frames - 1). */
+int32_t vc_vocoder_num_samples(const vc_vocoder_plan* plan, int32_t n_frames);
+size_t vc_vocoder_workspace_bytes(const vc_vocoder_plan* plan, int32_t batch, int32_t max_frames, int32_t trace);
+
+/* audio_lib.py:289-298: P = max(0, P); optional P = (mean(P)/mean(P**realse)) * P**realse (means
+ * over the utterance); amp = sqrt(db_to_power(P / P_dB_norm_factor - 80)).  d_P, d_amp
+ * [batch, max_frames, n_bins]; rows >= n_frames[b] are written as 0.  d_n_frames may be NULL. */
+int vc_power_to_amp(const float* d_P, const int32_t* d_n_frames, int32_t batch, int32_t max_frames, int32_t n_bins,
+                    float P_dB_norm_factor, float realse, float* d_amp, void* stream);
+
+/* audio_lib.py:249-274.  d_amp, d_phase0 [batch, max_frames, 1+n_fft/2] (phase0 in radians: the
+ * reference draws pi * U[0,1) on the host, audio_lib.py:255 -- the caller supplies it so a seeded
+ * run is reproducible); d_n_frames int32 [batch] or NULL (all max_frames); each utterance needs
+ * hop*(n_frames-1) > n_fft/2.  d_wav [batch, wav_stride] receives hop*(n_frames[b]-1) samples per
+ * utterance, zero beyond.  d_trace: NULL, or float32 [num_iters, batch] that receives
+ * sum_n (wav_i[n] - wav_{i-1}[n])^2 for i >= 1 (the reference's verbose print is
+ * sqrt(that / n_samples)); costs one extra launch per iteration.
+ * num_iters launches of the fused projection kernel + 1 overlap-add on `stream`. */
+int vc_griffin_lim_f32(const vc_vocoder_plan* plan, const float* d_amp, const float* d_phase0,
+                       const int32_t* d_n_frames, int32_t batch, int32_t max_frames, int32_t num_iters,
+                       float* d_wav, int32_t wav_stride, float* d_trace, void* d_workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* audio_lib.py:301-306 in place on d_wav [batch, wav_stride] (first hop*(n_frames[b]-1) samples):
+ * y[n] = x[n] + coeff*y[n-1] (skipped when coeff == 0), then y *= mean_abs_amp_norm / mean|y|
+ * (skipped when mean_abs_amp_norm <= 0). */
+int vc_inv_preemphasis_normalize(const vc_vocoder_plan* plan, float* d_wav, const int32_t* d_n_frames, int32_t batch,
+                                 int32_t max_frames, int32_t wav_stride, float coeff, float mean_abs_amp_norm,
+                                 void* stream);
+
 /* float32 <-> bf16 conversion of a contiguous buffer (weights preparation, I/O). */
 int vc_convert(const void* d_src, int32_t src_dtype, void* d_dst, int32_t dst_dtype, size_t n, void* stream);
 

@@ -112,6 +112,14 @@ _SIGS = {
                                C.c_float, _P]),
     'vc_gru_train_forward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     'vc_gru_backward': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    'vc_vocoder_plan_create': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
+    'vc_vocoder_plan_destroy': (None, [_P]),
+    'vc_vocoder_num_samples': (C.c_int32, [_P, C.c_int32]),
+    'vc_vocoder_workspace_bytes': (C.c_size_t, [_P, C.c_int32, C.c_int32, C.c_int32]),
+    'vc_power_to_amp': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P, _P]),
+    'vc_griffin_lim_f32': (C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P,
+                                     C.c_size_t, _P]),
+    'vc_inv_preemphasis_normalize': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _P]),
 }
 
 

@@ -3,10 +3,11 @@
 Mirrors /root/reference/test.py:46-306: ``compound`` (stitching of half-overlapped window
 predictions), ``conversion`` (non-overlapping windows) and ``conversion2`` (two passes shifted by
 half a window, stitched) -- the pure integer framing that turns an utterance's features into
-[N, n_timesteps, C] batches for ``decoder.predict`` and back.  Plotting, audio playback and wav
-writing (test.py:28-43, 171-188) are UI side effects and out of scope; the Griffin-Lim vocoder
-(audio_lib.from_power_to_wav) is a "next" row of SURVEY.md section 8f, so ``y_wav_true`` /
-``y_wav_pred`` are None unless a ``vocoder`` callable is supplied.
+[N, n_timesteps, C] batches for ``decoder.predict`` and back, followed by the Griffin-Lim vocoder
+(audio_lib.from_power_to_wav on the GPU, test.py:146-168).  Plotting, audio playback and wav
+writing (test.py:28-43, 171-188) are UI side effects and out of scope.  ``vocoder``: 'default' =
+audio_lib.from_power_to_wav, any callable with that signature, or None to skip audio synthesis
+(``y_wav_true`` / ``y_wav_pred`` are then None).
 """
 from collections import namedtuple
 
@@ -77,6 +78,9 @@ def _pad_all(mfcc, mel, stft, pad_len):
 def _vocode(vocoder, stft_true, stft_pred, cfg_d, n_iter, realse, giffin_lim_input):
     if vocoder is None:
         return None, None
+    if vocoder == 'default':
+        import audio_lib
+        vocoder = audio_lib.from_power_to_wav
     kw = dict(P_dB_norm_factor=cfg_d['P_dB_norm_factor'], pre_emphasis=cfg_d['pre_emphasis'],
               hop_length=cfg_d['hop_length'], win_length=cfg_d['win_length'],
               mean_abs_amp_norm=15 * cfg_d['mean_abs_amp_norm'], n_iter=n_iter, n_fft=cfg_d['n_fft'])
@@ -86,7 +90,7 @@ def _vocode(vocoder, stft_true, stft_pred, cfg_d, n_iter, realse, giffin_lim_inp
 
 def conversion2(decoder, mfcc, mel, stft, cfg_d, t_s=5, t_e=60, n_iter=200, output_path='./output',
                 file_name='y_wav', realse=1.0, save_output=False, giffin_lim_input=True, play_conversion=False,
-                vocoder=None):
+                vocoder='default'):
     """test.py:87-201: half-overlapped double pass + ``compound``."""
     n_times = cfg_d['n_timesteps']
     pad_len, n_s, n_e = window_plan(mfcc.shape[0], cfg_d, t_s, t_e)
@@ -115,7 +119,7 @@ def conversion2(decoder, mfcc, mel, stft, cfg_d, t_s=5, t_e=60, n_iter=200, outp
 
 def conversion(decoder, mfcc, mel, stft, cfg_d, t_s=5, t_e=60, n_iter=200, output_path='./output',
                file_name='y_wav', realse=1.0, save_output=False, giffin_lim_input=True, play_conversion=False,
-               vocoder=None):
+               vocoder='default'):
     """test.py:206-306: single pass over non-overlapping windows."""
     n_times = cfg_d['n_timesteps']
     pad_len, n_s, n_e = window_plan(mfcc.shape[0], cfg_d, t_s, t_e)

@@ -168,4 +168,45 @@ VC_HD int bin_of(int k1, int k2) {
     return 400 - k;
 }
 
+// ---- inverse direction (Griffin-Lim vocoder, vc_vocoder.hip) -------------------------------------
+// x[16 n1 + n2] = (1/400) sum_k1 W25^(-n1 k1) B[k1, n2],
+// B[k1, n2] = W400^(-n2 k1) sum_k2 W16^(-n2 k2) S[k1 + 25 k2]   (S hermitian: S[400-k] = conj S[k]).
+// B[25-k1, n2] = conj B[k1, n2], so k1 = 0..12 suffice and the 25-point stage is a
+// hermitian -> real transform.
+
+constexpr float COS25[25] = {1.0f, 0.96858316112863108f, 0.87630668004386358f, 0.72896862742141155f, 0.53582679497899655f, 0.30901699437494745f, 0.062790519529313527f, -0.1873813145857246f, -0.42577929156507272f, -0.63742398974868975f, -0.80901699437494734f, -0.92977648588825135f, -0.99211470131447776f, -0.99211470131447788f, -0.92977648588825146f, -0.80901699437494778f, -0.63742398974868952f, -0.42577929156507216f, -0.18738131458572463f, 0.062790519529312833f, 0.30901699437494723f, 0.53582679497899677f, 0.72896862742141122f, 0.87630668004386314f, 0.96858316112863097f};
+constexpr float SIN25[25] = {0.0f, 0.24868988716485479f, 0.48175367410171532f, 0.68454710592868862f, 0.84432792550201508f, 0.95105651629515353f, 0.99802672842827156f, 0.98228725072868872f, 0.90482705246601947f, 0.77051324277578925f, 0.58778525229247325f, 0.36812455268467814f, 0.12533323356430454f, -0.12533323356430429f, -0.36812455268467792f, -0.58778525229247269f, -0.77051324277578936f, -0.9048270524660198f, -0.98228725072868872f, -0.99802672842827156f, -0.95105651629515364f, -0.84432792550201496f, -0.68454710592868895f, -0.4817536741017161f, -0.24868988716485535f};
+
+// Inverse complex 16-point DFT (no 1/16): idft(z) = conj(dft(conj z)).
+VC_HD void cidft16(float* zr, float* zi, float* yr, float* yi) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) zi[i] = -zi[i];
+    cdft16(zr, zi, yr, yi);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) yi[i] = -yi[i];
+}
+
+// Hermitian 25-point inverse DFT (no 1/25): b[k1], k1 = 0..12 (Im b[0] ignored) -> x[0..24] real,
+//   x[n1] = b0 + 2 sum_{k=1..12} (br[k] cos(2 pi n1 k/25) - bi[k] sin(2 pi n1 k/25)).
+VC_HD void hdft25_real(const float* br, const float* bi, float* x) {
+#pragma unroll
+    for (int n1 = 0; n1 <= 12; ++n1) {
+        float e = 0.5f * br[0], o = 0.0f;
+#pragma unroll
+        for (int k = 1; k <= 12; ++k) {
+            e = fmaf(br[k], COS25[(n1 * k) % 25], e);
+            o = fmaf(bi[k], SIN25[(n1 * k) % 25], o);
+        }
+        x[n1] = 2.0f * (e - o);
+        if (n1 > 0) x[25 - n1] = 2.0f * (e + o);
+    }
+}
+
+// Spectrum bin (0..200) whose value (conjugated when k > 200) is S[k1 + 25 k2].
+VC_HD int src_bin(int k1, int k2, bool& conj) {
+    const int k = k1 + 25 * k2;
+    conj = k > 200;
+    return conj ? 400 - k : k;
+}
+
 }  // namespace vcfe

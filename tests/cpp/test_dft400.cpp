@@ -10,7 +10,7 @@ int main() {
     const double PI = 3.14159265358979323846;
     std::vector<float> x(400);
     unsigned s = 12345u;
-    double worst = 0.0, scale = 0.0;
+    double worst = 0.0, scale = 0.0, worst_inv = 0.0;
     for (int trial = 0; trial < 8; ++trial) {
         for (int n = 0; n < 400; ++n) {
             s = s * 1664525u + 1013904223u;
@@ -32,9 +32,33 @@ int main() {
         }
         std::vector<double> P(201, -1.0);
         int written = 0;
+        static float Br[13][16], Bi[13][16];
         for (int k1 = 0; k1 < 13; ++k1) {
             float yr[16], yi[16];
             vcfe::cdft16(Ar[k1], Ai[k1], yr, yi);
+            {   // inverse direction: the 16 values this k1 holds are S[k1 + 25 k2] (src_bin says which
+                // bin, conjugated above 200) -- check that claim against the naive DFT below, then
+                // run the inverse 16-point stage and the conjugate twiddle.
+                float zr[16], zi[16], br[16], bi[16];
+                for (int k2 = 0; k2 < 16; ++k2) { zr[k2] = yr[k2]; zi[k2] = yi[k2]; }
+                vcfe::cidft16(zr, zi, br, bi);
+                for (int n2 = 0; n2 < 16; ++n2) {
+                    const double a = 2.0 * PI * (double)(n2 * k1) / 400.0;
+                    vcfe::cmul(br[n2], bi[n2], (float)cos(a), (float)sin(a));
+                    Br[k1][n2] = br[n2]; Bi[k1][n2] = bi[n2];
+                }
+                for (int k2 = 0; k2 < 16; ++k2) {
+                    bool cj; const int b = vcfe::src_bin(k1, k2, cj);
+                    double re = 0, im = 0;
+                    for (int n = 0; n < 400; ++n) {
+                        double ang = -2.0 * PI * (double)((b * n) % 400) / 400.0;
+                        re += x[n] * cos(ang); im += x[n] * sin(ang);
+                    }
+                    if (cj) im = -im;
+                    const double e = fabs(re - yr[k2]) + fabs(im - yi[k2]);
+                    if (e > 2e-3) { printf("src_bin mismatch k1=%d k2=%d err %.3e\n", k1, k2, e); return 3; }
+                }
+            }
             for (int k2 = 0; k2 < 16; ++k2) {
                 int b = vcfe::bin_of(k1, k2);
                 if (b < 0) continue;
@@ -60,7 +84,22 @@ int main() {
             if (e > worst) worst = e;
         }
         scale = pmax;
+        // inverse 25-point hermitian stage: must give back 400 * x
+        double xmax = 0.0, xerr = 0.0;
+        for (int n2 = 0; n2 < 16; ++n2) {
+            float br[13], bi[13], xr[25];
+            for (int k1 = 0; k1 < 13; ++k1) { br[k1] = Br[k1][n2]; bi[k1] = Bi[k1][n2]; }
+            vcfe::hdft25_real(br, bi, xr);
+            for (int n1 = 0; n1 < 25; ++n1) {
+                const double ref = 400.0 * x[16 * n1 + n2];
+                xerr = fmax(xerr, fabs(xr[n1] - ref));
+                xmax = fmax(xmax, fabs(ref));
+            }
+        }
+        if (xerr / xmax > worst_inv) worst_inv = xerr / xmax;
     }
+    printf("inverse round trip max |x' - 400 x| / max = %.3e\n", worst_inv);
+    if (worst_inv > 5e-6) return 4;
     printf("max |P - Pref| / max(Pref) = %.3e (last pmax %.3e)\n", worst, scale);
     return worst < 2e-6 ? 0 : 2;
 }

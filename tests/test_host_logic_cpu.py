@@ -68,14 +68,14 @@ def test_conversion2_stitching_end_to_end():
     rng = np.random.RandomState(1)
     F = 1001
     mfcc, mel, stft = rng.standard_normal((F, 80)), rng.standard_normal((F, 80)), rng.standard_normal((F, 201))
-    r = conversion.conversion2(_FakeDecoder(), mfcc, mel, stft, cfg, t_s=0, t_e=60)
+    r = conversion.conversion2(_FakeDecoder(), mfcc, mel, stft, cfg, t_s=0, t_e=60, vocoder=None)
     assert r.mel_pred.shape == (1200, 3) and r.stft_pred.shape == (1200, 5) and r.phn_pred.shape == (1200, 4)
     assert r.y_wav_true is None and r.y_wav_pred is None
     # the echo decoder is pointwise, so stitching must reproduce the padded input exactly
     padded = np.concatenate([mfcc, np.zeros((199, 80))], 0)
     assert np.array_equal(r.mel_pred, padded[:, :3] * 2.0)
     assert np.array_equal(r.stft_true, np.concatenate([stft, np.zeros((199, 201))], 0))
-    r1 = conversion.conversion(_FakeDecoder(), mfcc[:400], mel[:400], stft[:400], cfg, t_s=0, t_e=60)
+    r1 = conversion.conversion(_FakeDecoder(), mfcc[:400], mel[:400], stft[:400], cfg, t_s=0, t_e=60, vocoder=None)
     assert r1.mel_pred.shape == (400, 3) and len(r1) == 6
 
 
