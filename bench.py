@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the hot path on MI355X.  Contract: prints ONE JSON line on rank 0.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload frontend|full]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full|frontend|train|vocoder]
 
 A "step" is one pass of the hot path over one synthetic batch that is already resident in
 HBM.  Multi-GPU: one process per GPU (torch.distributed.run), the utterance batch is sharded
@@ -20,6 +20,7 @@ Extra objects on the line: "roofline" (dominant kernel, HIP-event timed on the l
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -295,6 +296,66 @@ def bench_train(args, rank, world):
     return B * T, dt, extra, cfg
 
 
+def bench_vocoder(args, rank, world):
+    """Griffin-Lim vocoder: one step = from_power_to_wav on a batch of
+    predicted power spectrograms, 200 iterations as test.py:87 uses."""
+    import audio_lib
+    B, F, n_iter = 16, 1000, 200
+    g = torch.Generator().manual_seed(300 + rank)
+    wav = synth_audio(B, 80 * (F - 1), seed=300 + rank).cuda()
+    _, _, P = audio_lib.calc_MFCC_input_batch(wav, None, **FE_KW)
+    P = P[:, :F].contiguous()
+    ph = (torch.rand(B, F, 201, generator=g) * math.pi).cuda()
+    kw = dict(P_dB_norm_factor=0.01, pre_emphasis=0.97, hop_length=80, win_length=400, mean_abs_amp_norm=0.045,
+              n_iter=n_iter, n_fft=None, realse=1.0, phase0=ph)
+    for _ in range(args.warmup):
+        audio_lib.from_power_to_wav_batch(P, None, **kw)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = audio_lib.from_power_to_wav_batch(P, None, **kw)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    dt = time.perf_counter() - t0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    out = audio_lib.from_power_to_wav_batch(P, None, **kw)
+    e1.record()
+    torch.cuda.synchronize()
+    us_iter = e0.elapsed_time(e1) * 1e3 / n_iter
+    # per launch: every frame is gathered once (5 overlapping reads hit L2) and written once
+    alg_bytes = B * F * (2 * 400 + 201) * 4
+    extra = {'stages': {'us_per_iteration': round(us_iter, 2), 'iterations': n_iter,
+                        'audio_seconds_per_step': round(B * 80 * (F - 1) / 16000.0, 1)},
+             'roofline': {'bound': 'hbm', 'achieved': round(alg_bytes / (us_iter * 1e-6) / 1e9, 1), 'peak': 8000.0,
+                          'unit': 'GB/s', 'frac': round(alg_bytes / (us_iter * 1e-6) / 8e12, 4), 'traffic': None,
+                          'kernel': 'gl_iter400_kernel<false> (time per iteration from events around the 200-launch '
+                                    'chain; transform arithmetic and LDS traffic, not HBM, set its duration)'}}
+    cfg = {'workload': 'vocoder: from_power_to_wav, %d utterances x %d frames (5 s each), %d Griffin-Lim iterations, '
+                       'n_fft 400 hop 80' % (B, F, n_iter), 'frames_per_step_per_gpu': B * F}
+    return B * F, dt, extra, cfg
+
+
+def cpu_baseline_vocoder():
+    """oracle/vocoder_oracle.py (numpy float64 restatement of the librosa loop) on one utterance of
+    the same shape with 20 of the 200 iterations, scaled to 200."""
+    from oracle import frontend_oracle as fo
+    from oracle import vocoder_oracle as vo
+    F = 1000
+    wav = synth_audio(1, 80 * (F - 1), seed=300).numpy()[0]
+    P = fo.calc_MFCC_input(wav, **FE_KW)[2][:F]
+    t0 = time.perf_counter()
+    vo.from_power_to_wav(P, 0.01, 0.97, 80, 400, 0.045, n_iter=20, n_fft=None, seed=0)
+    dt = (time.perf_counter() - t0) * 10.0
+    return {'value': round(F / dt, 1), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+            'sample': '1 of the 16 utterances (1000 frames), 20 of the 200 iterations timed and scaled x10; '
+                      'oracle/vocoder_oracle.py (numpy restatement of librosa.istft/stft; single thread)'}
+
+
 def cpu_baseline_full():
     """Oracle timed on the host: front-end on 2 utterances (numpy) + encode/decode of 2 windows with
     torch-CPU float32 ops at the shipped sizes (all host threads)."""
@@ -352,7 +413,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--workload', default='full', choices=['full', 'frontend', 'train'])
+    ap.add_argument('--workload', default='full', choices=['full', 'frontend', 'train', 'vocoder'])
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
     ap.add_argument('--window-batch', type=int, default=64)
     ap.add_argument('--streams', type=int, default=3,
@@ -372,6 +433,8 @@ def main():
     elif args.workload == 'train':
         frames, dt, extra, cfg = bench_train(args, rank, world)
         args.no_cpu_baseline = True
+    elif args.workload == 'vocoder':
+        frames, dt, extra, cfg = bench_vocoder(args, rank, world)
     else:
         frames, dt, extra, cfg = bench_full(args, rank, world)
 
@@ -380,12 +443,13 @@ def main():
         line = {'metric': 'mel frames/sec', 'value': round(frames * world * args.steps / dt, 1), 'unit': 'frames/s',
                 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(dt / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak',
-                'vs_baseline': None, 'dtype': 'f32' if args.workload in ('frontend', 'train') else
+                'vs_baseline': None, 'dtype': 'f32' if args.workload in ('frontend', 'train', 'vocoder') else
                 ('bf16' if args.dtype == 'bfloat16' else 'f32'), 'data': 'synthetic',
                 'config': dict(cfg, parallelism='utterance-sharded x%d, no collective' % world)}
         line.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline_frontend() if args.workload == 'frontend' else cpu_baseline_full()
+            line['cpu_baseline'] = {'frontend': cpu_baseline_frontend, 'vocoder': cpu_baseline_vocoder}.get(
+                args.workload, cpu_baseline_full)()
         print(json.dumps(line))
     dist_util.finalize()
 

@@ -367,7 +367,7 @@ power_to_amp_kernel(const float* P, const int32_t* n_frames, int maxF, int nb, f
 struct vc_vocoder_plan {
     int32_t win_length, hop, N, nb, nov, span, span_g;
     float* d_tables;       // window[N] | tw400[416] | twg[2N]
-    size_t smem400, smem_gen;
+    size_t smem400, smem400_init, smem_gen;
 };
 
 extern "C" {
@@ -411,7 +411,8 @@ int vc_vocoder_plan_create(int32_t win_length, int32_t hop_length, int32_t n_fft
         (void)hipFree(p->d_tables); delete p;
         return vc::set_error(VC_ERR_HIP, "vocoder plan: hipMemcpy failed");
     }
-    p->smem400 = sizeof(float) * (400 + 416 + 2 * (VG * 13) * VA_STRIDE + VG * 201 + (size_t)std::max(p->span, VG * 201));
+    p->smem400 = sizeof(float) * (400 + 416 + 2 * (VG * 13) * VA_STRIDE + VG * 201 + (size_t)p->span);
+    p->smem400_init = sizeof(float) * (400 + 416 + 2 * (VG * 13) * VA_STRIDE + 2 * VG * 201);
     p->smem_gen = sizeof(float) * ((size_t)3 * N + 2 * VGG * p->nb + p->span_g);
     if (N != 400 && p->smem_gen > 160 * 1024) {
         (void)hipFree(p->d_tables); delete p;
@@ -496,7 +497,7 @@ int vc_griffin_lim_f32(const vc_vocoder_plan* p, const float* d_amp, const float
     for (int i = 0; i < num_iters; ++i) {
         a.prev = fr[cur]; a.next = fr[cur ^ 1];
         if (i == 0) {
-            if (fast) hipLaunchKernelGGL(gl_iter400_kernel<true>, grid, dim3(VT), smem, st, a);
+            if (fast) hipLaunchKernelGGL(gl_iter400_kernel<true>, grid, dim3(VT), p->smem400_init, st, a);
             else hipLaunchKernelGGL(gl_iter_generic_kernel<true>, grid, dim3(VT), smem, st, a);
         } else {
             if (fast) hipLaunchKernelGGL(gl_iter400_kernel<false>, grid, dim3(VT), smem, st, a);

@@ -4,16 +4,17 @@
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/r01
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 cd $R
 timeout -k 10 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log
 timeout -k 10 300 python bench.py > $O/bench_full.log 2>&1
 timeout -k 10 200 python bench.py --workload frontend --steps 50 --warmup 5 > $O/bench_frontend.log 2>&1
 timeout -k 10 300 python bench.py --workload train --steps 3 --warmup 1 > $O/bench_train.log 2>&1
+timeout -k 10 200 python bench.py --workload vocoder --steps 5 --warmup 1 > $O/bench_vocoder.log 2>&1
 timeout -k 10 200 python bench.py --dtype float32 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_full_f32.log 2>&1
 cd /tmp && export TMPDIR=/tmp
-for W in full frontend train; do
-  EXTRA="--steps 5 --warmup 1 --no-cpu-baseline"; [ $W = train ] && EXTRA="--steps 2 --warmup 1"
+for W in full frontend train vocoder; do
+  EXTRA="--steps 5 --warmup 1 --no-cpu-baseline"; [ $W = train ] && EXTRA="--steps 2 --warmup 1"; [ $W = vocoder ] && EXTRA="--steps 2 --warmup 1 --no-cpu-baseline"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$W -- python3 $R/bench.py --workload $W $EXTRA > $O/trace_$W.log 2>&1
   cp $O/trace_$W/*/*kernel_stats.csv $O/${W}_kernel_stats.csv 2>/dev/null
 done
@@ -26,7 +27,8 @@ import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 names = {'conv_kernelIDF16bLi0': 'conv_kernel_bf16_bank_step2', 'conv_kernelIDF16bLi1': 'conv_kernel_bf16_proj1_step2',
          'gru_resident_kernelILi256': 'gru_resident_256', 'fe_power400': 'fe_power400_kernel',
-         'fe_finalize': 'fe_finalize_kernel', 'fe_abssum': 'fe_abssum_kernel'}
+         'fe_finalize': 'fe_finalize_kernel', 'fe_abssum': 'fe_abssum_kernel',
+         'gl_iter400_kernel<false>': 'gl_iter400_kernel'}
 for f in glob.glob('$O/pmc_*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         for k, v in names.items():
@@ -42,4 +44,4 @@ for k, v in agg.items():
 json.dump(out, open('$O/pmc_summary.json', 'w'), indent=1, sort_keys=True)
 print(json.dumps({k: v.get('traffic_bytes_per_launch') for k, v in out.items()}))
 PY
-tail -2 $O/smoke.log; for f in bench_full bench_frontend bench_train bench_full_f32; do tail -1 $O/$f.log | cut -c1-330; done
+tail -2 $O/smoke.log; for f in bench_full bench_frontend bench_train bench_vocoder bench_full_f32; do tail -1 $O/$f.log | cut -c1-330; done

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Runs the dominant kernels of the hot path a few times each, stand-alone, so rocprofv3 (kernel
-trace or --pmc passes) sees clean dispatches:  python tools/prof_kernels.py [bank|proj1|gru|frontend|all]
+trace or --pmc passes) sees clean dispatches:  python tools/prof_kernels.py [bank|proj1|gru|frontend|vocoder|all]
 
 Shapes = the bench's full workload (64 windows x 400 frames, decoder step 2, bf16; front-end on
 32 x 4 s).  Prints the algorithmic bytes / FLOPs per launch used by bench.py's roofline."""
@@ -35,6 +35,10 @@ if what in ('frontend', 'all'):
     out = None
     for _ in range(reps):
         out = audio_lib.calc_MFCC_input_batch(wav, None, out=out, **bench.FE_KW)
+if what in ('vocoder', 'all'):
+    amp = torch.rand(16, 1000, 201, device='cuda') * 0.1
+    ph = torch.rand(16, 1000, 201, device='cuda') * 3.14159
+    audio_lib.griffin_lim_batch(amp, None, 400, 80, num_iters=4, phase0=ph)
 torch.cuda.synchronize()
 print('bank  : %.4g FLOP/launch ; operands: X %d B + W %d B, out %d B' % (
     2.0 * 256 * 128 * 528 * W * T, W * T * 256 * 2, 256 * 128 * 528 * 2, W * T * 4096 * 2))
