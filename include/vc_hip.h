@@ -349,6 +349,14 @@ int vc_inv_preemphasis_normalize(const vc_vocoder_plan* plan, float* d_wav, cons
                                  int32_t max_frames, int32_t wav_stride, float coeff, float mean_abs_amp_norm,
                                  void* stream);
 
+/* ---- on-device feature cache -----------------------------------
+ * dst[r, :] = src[index[r], :] for index[r] >= 0, else pad_row (zeros when d_pad_row is NULL).
+ * Rows are row_bytes wide (multiple of 4).  Replaces the h5py slicing + np.array stacking of
+ * sound_ds.py:262-350, ARCTIC_reader.py:277-362, TIMIT_reader.py:474-523 (and packs front-end
+ * output into the ragged cache, ARCTIC_reader.py:109-175 / TIMIT_reader.py:144-210). */
+int vc_gather_rows(const void* d_src, const int64_t* d_index, const void* d_pad_row, int64_t n_rows,
+                   int32_t row_bytes, void* d_dst, void* stream);
+
 /* float32 <-> bf16 conversion of a contiguous buffer (weights preparation, I/O). */
 int vc_convert(const void* d_src, int32_t src_dtype, void* d_dst, int32_t dst_dtype, size_t n, void* stream);
 

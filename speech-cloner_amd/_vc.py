@@ -112,6 +112,7 @@ _SIGS = {
                                C.c_float, _P]),
     'vc_gru_train_forward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     'vc_gru_backward': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    'vc_gather_rows': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     'vc_vocoder_plan_create': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
     'vc_vocoder_plan_destroy': (None, [_P]),
     'vc_vocoder_num_samples': (C.c_int32, [_P, C.c_int32]),

@@ -184,3 +184,34 @@ def test_two_process_gloo_sharding(tmp_path):
            os.path.join(ROOT, 'speech-cloner_amd')]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and 'GLOO_OK' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_dataset_filter_and_split_logic_match_oracle():
+    """sound_ds.py:116-211 on the host (no GPU: the cache is not built)."""
+    import sound_ds
+    from oracle import dataset_oracle as do
+    rng = np.random.RandomState(0)
+    n = 57
+    ds = {'wav': [np.zeros(int(L), np.float32) for L in rng.randint(1000, 90000, n)],
+          'spk_id': np.array(['a', 'b', 'c', 'd'])[rng.randint(0, 4, n)],
+          'ds_type': np.array(['TRAIN', 'TEST'])[rng.randint(0, 2, n)]}
+    cfg = {'sample_rate': 16000, 'hop_length': 80, 'win_length': 400, 'n_mfcc': 40, 'n_timesteps': 400,
+           'random_seed': 1, 'verbose': False, 'ds_norm': (0.0, 1.0)}
+    d = sound_ds.Sound_DS(cfg, ds, build_cache=False)
+    filters = [None, {}, {'spk_id': 'a'}, {'spk_id': ['a', 'c'], 'ds_type': 'TRAIN'}, {'spk_id': None, 'ds_type': 'TEST'}]
+    for typ in ('trn', 'val', 'tst'):
+        filters.append({'split_d': {'split_key': 'spk_id', 'split_type': typ, 'split_props_v': (0.6, 0.8)},
+                        'spk_id': ['a', 'b', 'd']})
+    for f in filters:
+        assert np.array_equal(d.get_ds_filter(f), do.get_ds_filter(ds, f)), f
+        if f is not None:
+            assert d.get_n_windows(0.3, f) == do.get_n_windows(ds, cfg, 0.3, f)
+    parts = [d.get_ds_filter({'split_d': {'split_key': 'spk_id', 'split_type': t, 'split_props_v': (0.6, 0.8)}})
+             for t in ('trn', 'val', 'tst')]
+    assert (parts[0].astype(int) + parts[1] + parts[2] == 1).all()           # a partition
+    with pytest.raises(Exception, match='no encontrado'):
+        d.get_ds_filter({'nope': 1})
+    with pytest.raises(Exception, match='split no reconocido'):
+        d.get_ds_filter({'split_d': {'split_key': 'spk_id', 'split_type': 'x', 'split_props_v': (0.1, 0.2)}})
+    with pytest.raises(Exception, match='tupla de len 2'):
+        d.get_ds_filter({'split_d': {'split_key': 'spk_id', 'split_type': 'trn', 'split_props_v': [0.1, 0.2]}})
