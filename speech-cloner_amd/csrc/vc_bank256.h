@@ -1,0 +1,23 @@
+// Internal interface between vc_gemm.hip (vc_conv_gemm dispatch) and vc_bank256.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+struct Bank256Pair {
+    const void* Bt0;      // narrower filter: [128][taps0 * Cin] bf16, K contiguous
+    const void* Bt1;      // wider filter:    [128][(taps0 + 1) * Cin]
+    int32_t taps0, pad_l, c_off0, c_off1;
+};
+
+struct Bank256Args {
+    const void* X;
+    int32_t M, T, Cin, ldx;
+    const float* epi_scale;
+    const float* epi_shift;
+    int32_t act;
+    void* C;
+    int32_t ldc, n_pairs;
+    Bank256Pair p[16];
+};
+
+int vc_launch_bank256(const Bank256Args& a, hipStream_t st);

@@ -1,0 +1,234 @@
+// conv1d_banks on 256 x 256 tiles, 8 waves, bf16 MFMA -- the deep-pipelined form of conv_kernel
+// (vc_gemm.hip) for the dominant launch of the path: the decoder's K-wide filter bank
+// (/root/reference/modules.py:144-166: K convolutions of width 1..K over the same input,
+// concatenated, batch-normalised, ReLU).
+//
+// Why a second kernel: the 128 x 128 / 4-wave structure reads one ds_read_b128 per MFMA, which
+// saturates the CU's LDS port at ~41 % of the matrix peak.  Here every wave
+// owns a 128 x 64 accumulator (128 VGPRs), so 24 fragment reads feed 32 MFMAs (LDS port 75 % busy
+// at full MFMA rate), and operands reach LDS by global_load_lds (no staging registers).
+//
+// Work decomposition: filter widths come in pairs (2p+1, 2p+2) that share TF's SAME left padding
+// (p), so tap j of both reads the same shifted activation rows; a block computes 256 frames x
+// (128 + 128) output channels of one pair.  K loop = channel slab (64) outer, tap inner:
+//   A  activation tile of 256 + 32 rows of one slab, resident in LDS for all taps (double
+//      buffered across slabs); tap j's fragments are the same image read j rows further down,
+//   B  per (slab, tap) a 256 x 64 weight tile (left half = narrower filter; absent at its
+//      missing last tap), double buffered, fetched one full tile ahead,
+//   one barrier per tile, placed before the LAST k-step of a tile: by then every wave has retired
+//      its reads of the tile (so its buffer may be refilled) and the next tile's loads, issued one
+//      tile earlier, are waited for with vmcnt(0) -- nobody waits at the tile boundary itself.
+// LDS rows are 128 B; the 16-byte slot of row r is XORed with (r >> 1) & 7, applied on the SOURCE
+// address of the LDS-direct loads (the LDS image of one wave instruction is linear), so the 16
+// lanes of a ds_read_b128 group hit 16 different bank groups.  SAME-padding zeros depend on
+// (output frame, tap) and are a per-lane select on the A fragment.
+#include "vc_common.h"
+#include "vc_bank256.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int NT = 512;
+constexpr int BM = 256;
+constexpr int A_ROWS = 288;                        // 256 + 32 halo rows
+constexpr int A_BYTES = A_ROWS * 128;
+constexpr int B_BYTES = 256 * 128;
+constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;   // 139,264
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)g,
+                                     (__attribute__((address_space(3))) void*)(uintptr_t)(uint32_t)(uintptr_t)l, 16, 0, 0);
+}
+
+__global__ void __launch_bounds__(NT, 1)
+bank256_kernel(Bank256Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* const As = smem;                             // [2][288][128]
+    char* const Bs = smem + 2 * A_BYTES;               // [2][256][128]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
+    const int wr = wid >> 2, wc = wid & 3;             // wave tile: rows wr*128.., cols wc*64..
+    const Bank256Pair pr = a.p[a.n_pairs - 1 - (int)blockIdx.y];   // widest pair first
+    const int m0 = blockIdx.x * BM;
+    const int ntap = pr.taps0 + 1;                     // taps of the wider filter
+    const int nslab = a.Cin >> 6;
+    const int ntiles = nslab * ntap;
+    const int pad_l = pr.pad_l;
+    const __bf16* X = reinterpret_cast<const __bf16*>(a.X);
+
+    // ---------------- staging roles (LDS-direct loads; one wave instruction = 8 rows = 1 KB)
+    const int srow = lane >> 3;                        // row within the 8-row block
+    const int pslot = lane & 7;                        // physical 16-byte slot
+    // A: row block rb = q*8 + wid (q = 0..4; q = 4 only for waves 0..3), LDS row rho = rb*8 + srow
+    const __bf16* a_src[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        const int rho = (q * 8 + wid) * 8 + srow;
+        const int g = min(max(m0 - pad_l + rho, 0), a.M - 1);
+        const int slot = pslot ^ ((rho >> 1) & 7);
+        a_src[q] = X + (size_t)g * a.ldx + slot * 8;
+    }
+    const int a_rows_needed = BM + ntap - 1;           // rows >= this are never read
+    // B: row block rb = q*8 + wid (q = 0..3), row n = rb*8 + srow; n < 128 -> narrower filter
+    const __bf16* b_src[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = (q * 8 + wid) * 8 + srow;
+        const int slot = pslot ^ ((n >> 1) & 7);
+        const bool left = n < 128;
+        const __bf16* Bt = reinterpret_cast<const __bf16*>(left ? pr.Bt0 : pr.Bt1);
+        const int K = (left ? pr.taps0 : ntap) * a.Cin;
+        b_src[q] = Bt + (size_t)(n & 127) * K + slot * 8;
+    }
+    auto stageA = [&](int cs, int buf) {
+        char* dst = As + buf * A_BYTES + wid * 1024;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int rb = q * 8 + wid;
+            if (rb * 8 < a_rows_needed && rb < A_ROWS / 8) glds16(a_src[q] + cs * 64, dst + q * 8192);
+        }
+    };
+    auto stageB = [&](int n, int buf) {
+        const int cs = n / ntap, j = n - cs * ntap;
+        const int koff = j * a.Cin + cs * 64;
+        char* dst = Bs + buf * B_BYTES + wid * 1024;
+        const bool has_left = j < pr.taps0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (q >= 2 || has_left) glds16(b_src[q] + koff, dst + q * 8192);
+    };
+
+    // ---------------- MFMA roles
+    const int li = lane & 31, lh = lane >> 5;
+    // A fragment (row tile i, k-step s, tap j): LDS row rho = wr*128 + i*32 + li + j, slot (2s+lh) ^ ((rho>>1)&7)
+    const int a_row0 = wr * 128 + li;
+    // B fragment (col tile c, k-step s): row n = wc*64 + c*32 + li; (n>>1)&7 = (li>>1)&7
+    const int xb = (li >> 1) & 7;
+    int b_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) b_off[s] = (wc * 64 + li) * 128 + (((2 * s + lh) ^ xb) << 4);
+    int jlo[4], jhi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = min(m0 + wr * 128 + i * 32 + li, a.M - 1);
+        const int t = m % a.T;
+        jlo[i] = max(0, pad_l - t);
+        jhi[i] = a.T - t + pad_l;
+    }
+    const bool left_wave = wc < 2;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
+
+    bf16x8 fa[2][4], fb[2][2];
+    int a_base = 0, a_o[4];                             // per-tap A addressing
+    auto tap_setup = [&](int n) {
+        const int cs = n / ntap, j = n - cs * ntap;
+        const int rho = a_row0 + j;
+        const int x = (rho >> 1) & 7;
+        a_base = (cs & 1) * A_BYTES + rho * 128;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) a_o[s] = ((2 * s + lh) ^ x) << 4;
+        return j;
+    };
+    auto load_frags = [&](int set, int s, int bbuf) {
+        const char* ap = As + a_base + a_o[s];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[set][i] = *reinterpret_cast<const bf16x8*>(ap + i * 4096);
+        const char* bp = Bs + bbuf * B_BYTES + b_off[s];
+        fb[set][0] = *reinterpret_cast<const bf16x8*>(bp);
+        fb[set][1] = *reinterpret_cast<const bf16x8*>(bp + 4096);
+    };
+
+    // ---------------- prologue
+    stageA(0, 0);
+    stageB(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ntiles > 1) stageB(1, 1);
+    if (nslab > 1) stageA(1, 1);
+    int j = tap_setup(0);
+    load_frags(0, 0, 0);
+
+    for (int n = 0; n < ntiles; ++n) {
+        // the narrower filter has no tap taps0: its waves multiply zeros that round (2 of 8 waves on
+        // 1 of taps0+1 tiles; cheaper than a branch, which de-pipelines the fragment reads)
+        const bool active = !(left_wave && j >= pr.taps0);
+        bool v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = active && j >= jlo[i] && j < jhi[i];
+        const bf16x8 zero = {};
+        int jn = j;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s < 3) {
+                load_frags(nxt, s + 1, n & 1);
+            } else {
+                // every read of tile n has been issued; retire them, publish tile n+1, recycle tile n's buffer
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (n + 2 < ntiles) stageB(n + 2, n & 1);
+                if (n + 1 < ntiles) {
+                    const int cs1 = (n + 1) / ntap;
+                    // first tile of a slab: bring in the slab after it (its buffer was last read a slab ago)
+                    if ((n + 1) - cs1 * ntap == 0 && cs1 + 1 < nslab) stageA(cs1 + 1, (cs1 + 1) & 1);
+                    jn = tap_setup(n + 1);
+                    load_frags(nxt, 0, (n + 1) & 1);
+                }
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bf16x8 av = v[i] ? fa[cur][i] : zero;
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, fb[cur][0], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, fb[cur][1], acc[i][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        j = jn;
+    }
+
+    // ---------------- epilogue: BatchNorm scale/shift + activation, bf16 store
+    const int c_off = left_wave ? pr.c_off0 : pr.c_off1;
+    __bf16* C = reinterpret_cast<__bf16*>(a.C);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int oc = c_off + (wc & 1) * 64 + c * 32 + li;
+        const float sv = a.epi_scale ? a.epi_scale[oc] : 1.0f;
+        const float bv = a.epi_shift ? a.epi_shift[oc] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gm = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (gm >= a.M) continue;
+                float val = acc[i][c][r] * sv + bv;
+                if (a.act == VC_ACT_RELU) val = fmaxf(val, 0.0f);
+                C[(size_t)gm * a.ldc + oc] = (__bf16)val;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int vc_launch_bank256(const Bank256Args& a, hipStream_t st) {
+    static bool attr_done = false;
+    if (!attr_done) {
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(bank256_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(bank256_kernel, dim3((a.M + BM - 1) / BM, a.n_pairs), dim3(NT), LDS_BYTES, st, a);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}

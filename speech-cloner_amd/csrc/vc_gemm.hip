@@ -17,7 +17,9 @@
 // before the MFMAs of slab t and written to the other LDS buffer after them; one barrier per slab.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include "vc_common.h"
+#include "vc_bank256.h"
 
 namespace {
 
@@ -744,6 +746,37 @@ template <typename T, int MI> int launch_mi(const vc_gemm_desc* d, const KArgs& 
     return launch_one<T, VC_GEMM_PLAIN, MI, 0>(d, ka, st);
 }
 
+// The filter-bank launch in its paired 256 x 256 form (vc_bank256.hip): bf16, plain operand, groups
+// (2p+1, 2p+2) taps wide with a common left padding, 128 filters each, BatchNorm/ReLU epilogue.
+bool bank256_ok(const vc_gemm_desc* d) {
+    const char* e = std::getenv("VC_BANK256");           // VC_BANK256=0: A/B switch back to conv_kernel
+    if ((e && e[0] == '0') || d->dtype != VC_BF16 || d->mode != VC_GEMM_PLAIN) return false;
+    if (d->n_groups < 2 || (d->n_groups & 1) || d->n_groups > 32 || d->N != 128 || d->Cin % 64 || d->M < 256) return false;
+    if (d->d_pro_scale || d->pro_relu || d->pro_pool || d->d_R || d->out_f32 || d->drop_keep > 0.0f) return false;
+    if (d->act != VC_ACT_NONE && d->act != VC_ACT_RELU) return false;
+    if ((reinterpret_cast<uintptr_t>(d->d_C) & 1) || d->ldx % 8) return false;
+    for (int g = 0; g < d->n_groups; g += 2) {
+        const vc_gemm_group& a = d->groups[g];
+        const vc_gemm_group& b = d->groups[g + 1];
+        if (b.taps != a.taps + 1 || a.pad_l != b.pad_l || b.taps > 32 || a.taps < 1) return false;
+    }
+    return true;
+}
+
+int launch_bank256(const vc_gemm_desc* d, hipStream_t st) {
+    Bank256Args b;
+    b.X = d->d_X; b.M = d->M; b.T = d->T; b.Cin = d->Cin; b.ldx = d->ldx;
+    b.epi_scale = d->d_epi_scale; b.epi_shift = d->d_epi_shift; b.act = d->act;
+    b.C = d->d_C; b.ldc = d->ldc; b.n_pairs = d->n_groups / 2;
+    for (int g = 0; g < d->n_groups; g += 2) {
+        Bank256Pair& p = b.p[g / 2];
+        p.Bt0 = d->groups[g].d_Bt; p.Bt1 = d->groups[g + 1].d_Bt;
+        p.taps0 = d->groups[g].taps; p.pad_l = d->groups[g].pad_l;
+        p.c_off0 = d->groups[g].c_off; p.c_off1 = d->groups[g + 1].c_off;
+    }
+    return vc_launch_bank256(b, st);
+}
+
 template <typename T> int launch(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
     // convolution-specialised kernel: every group has taps in [2, 32] (a grouped bank launch may
     // include its k = 1 member) and Cin is a whole number of channel slabs
@@ -754,6 +787,7 @@ template <typename T> int launch(const vc_gemm_desc* d, const KArgs& ka, hipStre
         if (d->groups[g].taps > max_taps) max_taps = d->groups[g].taps;
     }
     if (conv_ok && max_taps > 1) {
+        if (sizeof(T) == 2 && bank256_ok(d)) return launch_bank256(d, st);
         if (d->d_pro_scale || d->pro_relu) return launch_conv<T, 2>(d, ka, st);
         if (d->pro_pool) return launch_conv<T, 1>(d, ka, st);
         return launch_conv<T, 0>(d, ka, st);
