@@ -229,10 +229,11 @@ def bench_full(args, rank, world):
         try:
             pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_summary.json')))
             if args.dtype == 'bfloat16' and W == 64:
-                traffic = pm['conv_kernel_bf16_bank_step2']['traffic_bytes_per_launch']
+                traffic = pm['bank256_kernel_bf16_step2']['traffic_bytes_per_launch']
         except Exception:
             traffic = None
-        extra['roofline'] = {'kernel': 'conv_kernel<%s> (decoder step2 conv1d_banks, 32 groups)' % args.dtype,
+        kname = 'bank256_kernel' if args.dtype == 'bfloat16' else 'conv_kernel<float32>'
+        extra['roofline'] = {'kernel': '%s (decoder step2 conv1d_banks, 32 filter widths)' % kname,
                              'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                              'frac': round(ach / peak, 4), 'traffic': traffic,
                              'algorithmic_flop_per_launch': fl_bank, 'avg_kernel_ms': round(ms_bank, 4)}

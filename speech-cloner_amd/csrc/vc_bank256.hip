@@ -119,6 +119,17 @@ bank256_kernel(Bank256Args a) {
         jhi[i] = a.T - t + pad_l;
     }
     const bool left_wave = wc < 2;
+    // taps [J_lo, J_hi) need no select anywhere in this wave (wave-uniform: scalar branch per tile)
+    int J_lo = max(max(jlo[0], jlo[1]), max(jlo[2], jlo[3]));
+    int J_hi = min(min(jhi[0], jhi[1]), min(jhi[2], jhi[3]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        J_lo = max(J_lo, __shfl_xor(J_lo, o, 64));
+        J_hi = min(J_hi, __shfl_xor(J_hi, o, 64));
+    }
+    J_lo = __builtin_amdgcn_readfirstlane(J_lo);
+    J_hi = __builtin_amdgcn_readfirstlane(J_hi);
+    if (left_wave) J_hi = min(J_hi, pr.taps0);
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -158,10 +169,12 @@ bank256_kernel(Bank256Args a) {
     int j = tap_setup(0);
     load_frags(0, 0, 0);
 
-    for (int n = 0; n < ntiles; ++n) {
-        // the narrower filter has no tap taps0: its waves multiply zeros that round (2 of 8 waves on
-        // 1 of taps0+1 tiles; cheaper than a branch, which de-pipelines the fragment reads)
-        const bool active = !(left_wave && j >= pr.taps0);
+#ifndef B256_RP
+#define B256_RP 2        // fragment-read placement: 0 = ahead of the step's MFMAs, 1 = between them, 2 = pinned after 2 MFMAs
+#endif
+    // one K tile (4 k-steps of 8 MFMAs); MASK = some row of this wave sees SAME padding at this tap
+    auto tile = [&](int n, const bool need_mask) {
+        const bool active = !(left_wave && j >= pr.taps0);     // the narrower filter has no tap taps0
         bool v[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = active && j >= jlo[i] && j < jhi[i];
@@ -170,51 +183,125 @@ bank256_kernel(Bank256Args a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
-            if (s < 3) {
-                load_frags(nxt, s + 1, n & 1);
-            } else {
+            bool have_next = !(a.dbg & 16);
+            int nb = n & 1;
+            if (s == 3) {
                 // every read of tile n has been issued; retire them, publish tile n+1, recycle tile n's buffer
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (n + 2 < ntiles) stageB(n + 2, n & 1);
-                if (n + 1 < ntiles) {
+                if (!(a.dbg & 8)) __syncthreads();
+                if (n + 2 < ntiles && !(a.dbg & 4)) stageB(n + 2, n & 1);
+                have_next = n + 1 < ntiles && !(a.dbg & 16);
+                if (have_next) {
                     const int cs1 = (n + 1) / ntap;
                     // first tile of a slab: bring in the slab after it (its buffer was last read a slab ago)
-                    if ((n + 1) - cs1 * ntap == 0 && cs1 + 1 < nslab) stageA(cs1 + 1, (cs1 + 1) & 1);
+                    if ((n + 1) - cs1 * ntap == 0 && cs1 + 1 < nslab && !(a.dbg & 4)) stageA(cs1 + 1, (cs1 + 1) & 1);
                     jn = tap_setup(n + 1);
-                    load_frags(nxt, 0, (n + 1) & 1);
                 }
+                nb = (n + 1) & 1;
             }
-            __builtin_amdgcn_s_setprio(1);
+            const int sn = (s + 1) & 3;
+            const char* ap = As + a_base + a_o[sn];
+            const char* bp = Bs + nb * B_BYTES + b_off[sn];
+            if (need_mask) {                                   // wave-uniform: scalar branch around 16 selects
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bf16x8 av = v[i] ? fa[cur][i] : zero;
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, fb[cur][0], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, fb[cur][1], acc[i][1], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) fa[cur][i] = v[i] ? fa[cur][i] : zero;
             }
+            bf16x8* av = fa[cur];
+#if B256_RP == 0
+            if (have_next) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[nxt][i] = *reinterpret_cast<const bf16x8*>(ap + i * 4096);
+                fb[nxt][0] = *reinterpret_cast<const bf16x8*>(bp);
+                fb[nxt][1] = *reinterpret_cast<const bf16x8*>(bp + 4096);
+            }
+#endif
+            __builtin_amdgcn_s_setprio(1);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][0], av[0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][1], av[0], acc[0][1], 0, 0, 0);
+#if B256_RP != 0
+            if (have_next) {
+                fa[nxt][0] = *reinterpret_cast<const bf16x8*>(ap);
+                fa[nxt][1] = *reinterpret_cast<const bf16x8*>(ap + 4096);
+            }
+#endif
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][0], av[1], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][1], av[1], acc[1][1], 0, 0, 0);
+#if B256_RP != 0
+            if (have_next) {
+                fa[nxt][2] = *reinterpret_cast<const bf16x8*>(ap + 2 * 4096);
+                fa[nxt][3] = *reinterpret_cast<const bf16x8*>(ap + 3 * 4096);
+            }
+#endif
+            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][0], av[2], acc[2][0], 0, 0, 0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][1], av[2], acc[2][1], 0, 0, 0);
+#if B256_RP != 0
+            if (have_next) {
+                fb[nxt][0] = *reinterpret_cast<const bf16x8*>(bp);
+                fb[nxt][1] = *reinterpret_cast<const bf16x8*>(bp + 4096);
+            }
+#endif
+            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][0], av[3], acc[3][0], 0, 0, 0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][1], av[3], acc[3][1], 0, 0, 0);
+#if B256_RP == 2
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+#endif
             __builtin_amdgcn_s_setprio(0);
         }
         j = jn;
+    };
+    const int nrun = (a.dbg & 1) ? 0 : ntiles;
+    for (int n = 0; n < nrun; ++n) {
+        tile(n, !(j >= J_lo && j < J_hi));
     }
 
-    // ---------------- epilogue: BatchNorm scale/shift + activation, bf16 store
-    const int c_off = left_wave ? pr.c_off0 : pr.c_off1;
-    __bf16* C = reinterpret_cast<__bf16*>(a.C);
+    // ---------------- epilogue: BatchNorm scale/shift + activation -> bf16 tile in LDS -> full-row stores
+    // The weights are the MFMA's first operand, so a lane holds ONE frame (row li of the 32 x 32
+    // tile) and, per register quad q, 4 consecutive channels 8q + 4lh + {0..3}: 8-byte LDS writes.
+    constexpr int EP = 528;                            // LDS row pitch of the [256][256] bf16 tile
+    __syncthreads();                                   // all fragment reads retired; no load in flight
+    {
+        const int c_off = left_wave ? pr.c_off0 : pr.c_off1;
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const int oc = c_off + (wc & 1) * 64 + c * 32 + li;
-        const float sv = a.epi_scale ? a.epi_scale[oc] : 1.0f;
-        const float bv = a.epi_shift ? a.epi_shift[oc] : 0.0f;
+        for (int c = 0; c < 2; ++c) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+            for (int q = 0; q < 4; ++q) {
+                const int chl = (wc & 1) * 64 + c * 32 + 8 * q + 4 * lh;       // channel within the filter
+                float4 sv = make_float4(1.0f, 1.0f, 1.0f, 1.0f), bv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (a.epi_scale) sv = *reinterpret_cast<const float4*>(a.epi_scale + c_off + chl);
+                if (a.epi_shift) bv = *reinterpret_cast<const float4*>(a.epi_shift + c_off + chl);
+                const float svv[4] = {sv.x, sv.y, sv.z, sv.w}, bvv[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wr * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (gm >= a.M) continue;
-                float val = acc[i][c][r] * sv + bv;
-                if (a.act == VC_ACT_RELU) val = fmaxf(val, 0.0f);
-                C[(size_t)gm * a.ldc + oc] = (__bf16)val;
+                for (int i = 0; i < 4; ++i) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float val = acc[i][c][4 * q + e] * svv[e] + bvv[e];
+                        if (a.act == VC_ACT_RELU) val = fmaxf(val, 0.0f);
+                        o[e] = (__bf16)val;
+                    }
+                    const int row = wr * 128 + i * 32 + li;
+                    const int col = wc * 64 + c * 32 + 8 * q + 4 * lh;             // column of the 256-wide pair tile
+                    *reinterpret_cast<bf16x4*>(smem + row * EP + col * 2) = o;
+                }
             }
+        }
+    }
+    __syncthreads();
+    {
+        const int l16 = tid & 15, hr = tid >> 4;           // 16 lanes x 16 B = one 128-channel half row
+        __bf16* C = reinterpret_cast<__bf16*>(a.C);
+#pragma unroll 4
+        for (int pss = 0; pss < 16; ++pss) {
+            const int h = pss * 32 + hr;                   // half-row index: row = h >> 1, half = h & 1
+            const int row = h >> 1, half = h & 1;
+            const int gm = m0 + row;
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(smem + row * EP + half * 256 + l16 * 16);
+            // streaming store: the 210 MB output must not displace the weight tiles from L2
+            if (gm < a.M && !(a.dbg & 2))
+                __builtin_nontemporal_store(vv, reinterpret_cast<bf16x8*>(C + (size_t)gm * a.ldc + (half ? pr.c_off1 : pr.c_off0) + l16 * 8));
         }
     }
 }

@@ -754,11 +754,12 @@ bool bank256_ok(const vc_gemm_desc* d) {
     if (d->n_groups < 2 || (d->n_groups & 1) || d->n_groups > 32 || d->N != 128 || d->Cin % 64 || d->M < 256) return false;
     if (d->d_pro_scale || d->pro_relu || d->pro_pool || d->d_R || d->out_f32 || d->drop_keep > 0.0f) return false;
     if (d->act != VC_ACT_NONE && d->act != VC_ACT_RELU) return false;
-    if ((reinterpret_cast<uintptr_t>(d->d_C) & 1) || d->ldx % 8) return false;
+    if ((reinterpret_cast<uintptr_t>(d->d_C) & 15) || d->ldx % 8 || d->ldc % 8) return false;
     for (int g = 0; g < d->n_groups; g += 2) {
         const vc_gemm_group& a = d->groups[g];
         const vc_gemm_group& b = d->groups[g + 1];
         if (b.taps != a.taps + 1 || a.pad_l != b.pad_l || b.taps > 32 || a.taps < 1) return false;
+        if (a.c_off % 8 || b.c_off % 8) return false;
     }
     return true;
 }
@@ -773,6 +774,12 @@ int launch_bank256(const vc_gemm_desc* d, hipStream_t st) {
         p.Bt0 = d->groups[g].d_Bt; p.Bt1 = d->groups[g + 1].d_Bt;
         p.taps0 = d->groups[g].taps; p.pad_l = d->groups[g].pad_l;
         p.c_off0 = d->groups[g].c_off; p.c_off1 = d->groups[g + 1].c_off;
+    }
+    b.dbg = 0;
+    if (const char* dbg = std::getenv("VC_BANK256_DBG")) b.dbg = std::atoi(dbg);
+    if (const char* only = std::getenv("VC_BANK256_ONLY")) {     // measurement hook: launch one pair alone
+        const int p = std::atoi(only);
+        if (p >= 0 && p < b.n_pairs) { b.p[0] = b.p[p]; b.n_pairs = 1; }
     }
     return vc_launch_bank256(b, st);
 }
