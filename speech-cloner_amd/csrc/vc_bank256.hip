@@ -93,12 +93,14 @@ bank256_kernel(Bank256Args a) {
     };
     auto stageB = [&](int n, int buf) {
         const int cs = n / ntap, j = n - cs * ntap;
-        const int koff = j * a.Cin + cs * 64;
+        // At the wider filter's extra tap the narrower one has no weights: its half of the tile is
+        // filled with its LAST tap again.  Those waves multiply zeroed activations there, and the
+        // zeros need finite partners (stale LDS bytes may decode to Inf/NaN: 0 * Inf = NaN).
+        const int koffR = j * a.Cin + cs * 64;
+        const int koffL = min(j, pr.taps0 - 1) * a.Cin + cs * 64;
         char* dst = Bs + buf * B_BYTES + wid * 1024;
-        const bool has_left = j < pr.taps0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            if (q >= 2 || has_left) glds16(b_src[q] + koff, dst + q * 8192);
+        for (int q = 0; q < 4; ++q) glds16(b_src[q] + (q < 2 ? koffL : koffR), dst + q * 8192);
     };
 
     // ---------------- MFMA roles
@@ -183,14 +185,14 @@ bank256_kernel(Bank256Args a) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int cur = s & 1, nxt = cur ^ 1;
-            bool have_next = !(a.dbg & 16);
+            bool have_next = true;
             int nb = n & 1;
             if (s == 3) {
                 // every read of tile n has been issued; retire them, publish tile n+1, recycle tile n's buffer
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 if (!(a.dbg & 8)) __syncthreads();
                 if (n + 2 < ntiles && !(a.dbg & 4)) stageB(n + 2, n & 1);
-                have_next = n + 1 < ntiles && !(a.dbg & 16);
+                have_next = n + 1 < ntiles;
                 if (have_next) {
                     const int cs1 = (n + 1) / ntap;
                     // first tile of a slab: bring in the slab after it (its buffer was last read a slab ago)

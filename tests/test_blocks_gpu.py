@@ -110,6 +110,42 @@ def test_conv1d_banks(dtype, K, cin):
     _close(y, ref, TOL[dtype], 'banks K=%d' % K)
 
 
+@pytest.mark.parametrize('N,T,cin,K', [(3, 100, 128, 32), (5, 333, 64, 8), (2, 400, 256, 32), (1, 256, 64, 2)])
+def test_conv1d_banks_paired_256_tile_kernel(N, T, cin, K, monkeypatch):
+    """bf16 banks with >= 256 frames, 64-channel slabs and an even K run on vc_bank256.hip (filter
+    widths paired, 256 x 256 tiles).  Checked against the oracle at the bf16 tolerance and, bit for
+    bit, against conv_kernel (same products in the same order), with LDS left full of NaN by the
+    kernel before it (stale LDS bytes once leaked into the narrower filter's missing tap)."""
+    import modules
+    import training
+    rng = np.random.RandomState(K + T)
+    st = _store('bfloat16')
+    x = torch.from_numpy(rng.standard_normal((N, T, cin)).astype(np.float32))
+    xd = modules.convert(x.cuda(), st.dtype)
+    with modules.variable_store(st), modules.variable_scope('e'):
+        modules.conv1d_banks(xd, K=K, is_training=False)
+        for nm in ('beta', 'gamma', 'moving_mean', 'moving_variance'):
+            v = rng.uniform(0.5, 1.5, 128 * K) if nm in ('gamma', 'moving_variance') else rng.uniform(-0.3, 0.3, 128 * K)
+            st.assign('e/conv1d_banks/bn/' + nm, v.astype(np.float32))
+        monkeypatch.setenv('VC_BANK256', '0')
+        y_old = modules.conv1d_banks(xd, K=K, is_training=False)
+        monkeypatch.setenv('VC_BANK256', '1')
+        nan = torch.full((4096, 2048), float('nan'), device='cuda')
+        out = torch.empty(2048, device='cuda')
+        ys = []
+        for _ in range(3):
+            training._Ops.col_sum(nan, 4096, 2048, 2048, out)          # reduces through LDS on every CU
+            ys.append(modules.conv1d_banks(xd, K=K, is_training=False))
+    torch.cuda.synchronize()
+    for y in ys:
+        assert not torch.isnan(y.float()).any()
+        assert torch.equal(y, y_old)
+    cast = lambda t: t.float().bfloat16().double()
+    w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
+    ref = mo.conv1d_banks(cast(x), w, 'e/conv1d_banks', K)
+    _close(ys[0], ref, TOL['bfloat16'], 'banks256 K=%d' % K)
+
+
 @pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
 @pytest.mark.parametrize('H', [40, 128, 72])
 def test_highwaynet(dtype, H):
