@@ -184,6 +184,67 @@ template <int MI> struct Mma<__bf16, MI> {
     }
 };
 
+
+// Epilogue of the 128-column tile kernels: scale/shift, activation, dropout and residual per
+// accumulator element, then the tile goes through LDS so that global memory sees whole 16-byte
+// chunks of a row (a lane of the 32 x 32 MFMA result owns one column: storing straight from the
+// accumulators writes 2-byte elements 64 B apart per row, which costs more than the K loop of the
+// short-K dense layers).  smem: the kernel's operand buffers, free after the last barrier.
+template <typename T, int MI>
+__device__ __forceinline__ void epilogue_tile(const KArgs& a, const KGroup& grp, char* smem, const f32x16 (&acc)[MI][2],
+                                              int m0, int n0, int row_w, int wn, int lane, int tid) {
+    constexpr int BM = 64 * MI;
+    const bool f32o = a.out_f32 || sizeof(T) == 4;
+    const int es = f32o ? 4 : 2;
+    const int pitch = 128 * es + 16;
+    const int i = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int lcol = wn * 64 + ni * 32 + i;
+        const int gn = min(n0 + lcol, a.N - 1);
+        const int oc = grp.c_off + gn;
+        const float s = a.epi_scale ? a.epi_scale[oc] : 1.0f;
+        const float b = a.epi_shift ? a.epi_shift[oc] : 0.0f;
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int lrow = row_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int gm = min(m0 + lrow, a.M - 1);
+                float v = act_fn(acc[mi][ni][r] * s + b, a.act);
+                if (a.drop_keep > 0.0f)
+                    v = drop_keep_elem((unsigned long long)gm * a.ldc + oc, a.drop_seed, a.drop_keep) ? v / a.drop_keep : 0.0f;
+                if (a.R) v += to_f32(reinterpret_cast<const T*>(a.R)[(size_t)gm * a.ldr + gn]);
+                char* dst = smem + lrow * pitch + lcol * es;
+                if (f32o) *reinterpret_cast<float*>(dst) = v;
+                else *reinterpret_cast<__bf16*>(dst) = (__bf16)v;
+            }
+        }
+    }
+    __syncthreads();
+    const int chunk = 16 / es;                           // elements per 16-byte chunk
+    const int cpr = 128 / chunk;                          // chunks per tile row
+    char* C = reinterpret_cast<char*>(a.C);
+    const bool vec_ok = ((reinterpret_cast<uintptr_t>(C) & 15) == 0) && ((a.ldc * es) % 16 == 0) &&
+                        (((grp.c_off + n0) * es) % 16 == 0);
+    for (int idx = tid; idx < BM * cpr; idx += GEMM_THREADS) {
+        const int row = idx / cpr, ch = idx - row * cpr;
+        const int gm = m0 + row, gn0 = n0 + ch * chunk;
+        if (gm >= a.M || gn0 >= a.N) continue;
+        const char* src = smem + row * pitch + ch * 16;
+        char* dst = C + ((size_t)gm * a.ldc + grp.c_off + gn0) * es;
+        if (vec_ok && gn0 + chunk <= a.N) {
+            *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(src);
+        } else {
+            const int n = min(chunk, a.N - gn0);
+            for (int e = 0; e < n; ++e) {
+                if (f32o) reinterpret_cast<float*>(dst)[e] = reinterpret_cast<const float*>(src)[e];
+                else reinterpret_cast<unsigned short*>(dst)[e] = reinterpret_cast<const unsigned short*>(src)[e];
+            }
+        }
+    }
+}
+
 // PRO: 0 = plain operand, 1 = time max-pool of the operand, 2 = per-channel affine (+relu)
 // (+ pool) -- the training path's "normalise the previous layer on the fly".
 template <typename T, int MODE, int MI, int PRO>
@@ -312,27 +373,7 @@ gemm_kernel(KArgs a) {
     // ---------------------------------------------------------------------------- epilogue
     const int i = lane & 31, h = lane >> 5;
     if (MODE == VC_GEMM_PLAIN) {
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const int gn = n0 + wn * 64 + ni * 32 + i;
-            if (gn >= a.N) continue;
-            const int oc = grp.c_off + gn;
-            const float s = a.epi_scale ? a.epi_scale[oc] : 1.0f;
-            const float b = a.epi_shift ? a.epi_shift[oc] : 0.0f;
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int gm = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (gm >= a.M) continue;
-                    float v = act_fn(acc[mi][ni][r] * s + b, a.act);
-                    if (a.drop_keep > 0.0f)
-                        v = drop_keep_elem((unsigned long long)gm * a.ldc + oc, a.drop_seed, a.drop_keep) ? v / a.drop_keep : 0.0f;
-                    if (a.R) v += to_f32(reinterpret_cast<const T*>(a.R)[(size_t)gm * a.ldr + gn]);
-                    store_out<T>(a.C, (size_t)gm * a.ldc + oc, v, a.out_f32);
-                }
-            }
-        }
+        epilogue_tile<T, MI>(a, grp, smem, acc, m0, n0, wm * 32 * MI, wn, lane, tid);
     } else {
         // highway: columns come in (32 x dense1 | 32 x dense2) pairs; output unit index:
         const int hc = (n0 + wn * 64) / 2 + i;
@@ -372,7 +413,9 @@ gemm_kernel(KArgs a) {
 // address = one per-slab base + compile-time immediates).
 constexpr int CONV_MAX_TAPS = 32;
 constexpr int CROWB = ROWB;
-constexpr int conv_lds_bytes() { return (128 + CONV_MAX_TAPS - 1) * CROWB + 2 * BN * CROWB; }   // A | B0 B1
+constexpr int conv_lds_bytes() {                       // A | B0 B1, and room for the f32 output tile of the epilogue
+    return (128 + CONV_MAX_TAPS - 1) * CROWB + 2 * BN * CROWB > 128 * 528 ? (128 + CONV_MAX_TAPS - 1) * CROWB + 2 * BN * CROWB : 128 * 528;
+}
 __device__ __forceinline__ int swz(int row, int chunk) { return row * CROWB + (chunk << 4); }
 
 template <typename T, int PRO>
@@ -555,28 +598,7 @@ conv_kernel(KArgs a) {
     }
 
     // ---------------------------------------------------------------------------- epilogue
-    const int i = li, h = lh;
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int gn = n0 + wn * 64 + ni * 32 + i;
-        if (gn >= a.N) continue;
-        const int oc = grp.c_off + gn;
-        const float sv = a.epi_scale ? a.epi_scale[oc] : 1.0f;
-        const float bv = a.epi_shift ? a.epi_shift[oc] : 0.0f;
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (gm >= a.M) continue;
-                float v = act_fn(acc[mi][ni][r] * sv + bv, a.act);
-                if (a.drop_keep > 0.0f)
-                    v = drop_keep_elem((unsigned long long)gm * a.ldc + oc, a.drop_seed, a.drop_keep) ? v / a.drop_keep : 0.0f;
-                if (a.R) v += to_f32(reinterpret_cast<const T*>(a.R)[(size_t)gm * a.ldr + gn]);
-                store_out<T>(a.C, (size_t)gm * a.ldc + oc, v, a.out_f32);
-            }
-        }
-    }
+    epilogue_tile<T, MI>(a, grp, smem, acc, m0, n0, wm * 64, wn, lane, tid);
 }
 
 template <typename T, int PRO> int launch_conv(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
