@@ -182,6 +182,29 @@ def test_gru_bidirectional(dtype, H, T):
     _close(y, ref, 5e-5 if dtype == 'float32' else 3e-2, 'gru H=%d' % H)
 
 
+@pytest.mark.parametrize('H,T,N', [(128, 60, 3), (256, 40, 35), (256, 24, 16), (128, 50, 33)])
+def test_gru_mfma_recurrence(H, T, N, monkeypatch):
+    """The 16-sequences-per-workgroup MFMA recurrence (chosen by itself from 32 sequences up, forced
+    here) against the oracle, incl. partly filled sequence groups, and run-to-run identical."""
+    import modules
+    rng = np.random.RandomState(H + T + N)
+    st = _store('bfloat16')
+    x = torch.from_numpy((0.7 * rng.standard_normal((N, T, H))).astype(np.float32))
+    xd = modules.convert(x.cuda(), st.dtype)
+    monkeypatch.setenv('VC_GRU_MFMA', '1')
+    with modules.variable_store(st), modules.variable_scope('g'):
+        y = modules.gru(xd, num_units=H, bidirection=True)
+        y2 = modules.gru(xd, num_units=H, bidirection=True)
+        monkeypatch.setenv('VC_GRU_MFMA', '0')
+        yv = modules.gru(xd, num_units=H, bidirection=True)
+    assert torch.equal(y, y2)
+    cast = lambda t: t.float().bfloat16().double()
+    w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
+    ref = mo.gru_bidirectional(cast(x), w, 'g/gru')
+    _close(y, ref, 3e-2, 'gru mfma H=%d' % H)
+    assert (y.float() - yv.float()).abs().max().item() < 2e-2          # the two kernels agree to bf16 rounding
+
+
 def test_softmax_argmax_exact_ties_and_padding():
     import modules
     rng = np.random.RandomState(1)

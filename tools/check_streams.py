@@ -1,0 +1,29 @@
+import os, sys, json, contextlib, io
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'speech-cloner_amd')):
+    sys.path.insert(0, p)
+import numpy as np, torch
+from encoder import encoder_spec_phn
+from decoder import decoder_specs
+from aux_func import load_cfg_d
+hp = os.path.join(ROOT, 'speech-cloner_amd', 'hp')
+with contextlib.redirect_stdout(io.StringIO()):
+    ec = load_cfg_d(os.path.join(hp, 'encoder_cfg_d.json')); dc = load_cfg_d(os.path.join(hp, 'decoder_cfg_d.json'))
+    ec.update(is_training=False, compute_dtype='bfloat16', model_path=os.path.join(ROOT, 'tests', 'golden', 'enc_14_ckpt'))
+    dc.update(is_training=False, compute_dtype='bfloat16')
+    enc = encoder_spec_phn(ec, None); enc.restore()
+    dec = decoder_specs(dc, None, enc)
+g = np.load(os.path.join(ROOT, 'tests', 'golden', 'encoder_fwd.npz'))
+x = np.concatenate([g['x'], g['x'][::-1] * 0.5, g['x'] * 0.25], 0)
+NREP = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+runs = [dec.predict(x, batch_size=2, n_streams=1) for _ in range(3)] + [dec.predict(x, batch_size=2, n_streams=3) for _ in range(NREP)]
+for k, r in enumerate(runs):
+    msg = []
+    for name, u, v in zip(('mel', 'stft', 'phn'), runs[0], r):
+        d = np.abs(u - v)
+        bad = np.argwhere(d > 0)
+        msg.append('%s: %d diffs max %.3g nan %d%s' % (name, len(bad), d.max() if len(bad) else 0.0, int(np.isnan(v).sum()),
+                                                       (' windows ' + str(sorted(set(bad[:, 0].tolist())))) if len(bad) else ''))
+    if k < 3 or 'diffs max 0 ' not in msg[0] or ' 0 diffs' not in msg[1] or ' 0 diffs' not in msg[2]:
+        print('run %d (%s): %s' % (k, 'seq' if k < 3 else '3 streams', '; '.join(msg)))
+print('done', len(runs))
