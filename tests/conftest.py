@@ -19,6 +19,20 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 REFERENCE = '/root/reference'
 
 
+def poison_gpu_state():
+    """Leaves NaN where stale bytes could be picked up by a kernel that reads something it never
+    wrote: in LDS (a reduction over NaN on every CU) and in the free blocks of torch's caching
+    allocator (so the next torch.empty() hands out NaN-filled memory)."""
+    import torch
+    import training
+    nan = torch.full((4096, 2048), float('nan'), device='cuda')
+    out = torch.empty(2048, device='cuda')
+    training._Ops.col_sum(nan, 4096, 2048, 2048, out)
+    junk = [torch.full((n,), float('nan'), device='cuda') for n in (1 << 26, 1 << 24, 1 << 22, 1 << 20, 1 << 18)]
+    torch.cuda.synchronize()
+    del junk, nan, out
+
+
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
