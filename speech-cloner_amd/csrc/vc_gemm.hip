@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include "vc_common.h"
 #include "vc_bank256.h"
+#include "vc_conv256.h"
 
 namespace {
 
@@ -806,7 +807,32 @@ int launch_bank256(const vc_gemm_desc* d, hipStream_t st) {
     return vc_launch_bank256(b, st);
 }
 
+// Single-filter bf16 convolutions / dense layers with a long K on the deep-pipelined 128-row tiles
+// (vc_conv256.hip): plain operand or non-negative max-pool, N a multiple of 128, taps <= 7.
+bool conv256_ok(const vc_gemm_desc* d) {
+    const char* e = std::getenv("VC_CONV256");           // VC_CONV256=0: A/B switch back to conv_kernel / gemm_kernel
+    if ((e && e[0] == '0') || d->dtype != VC_BF16 || d->mode != VC_GEMM_PLAIN || d->n_groups != 1) return false;
+    const vc_gemm_group& g = d->groups[0];
+    if (d->N % 128 || d->Cin % 64 || d->M < 128 || g.taps > 7 || g.taps * d->Cin < 1024) return false;
+    if (d->d_pro_scale || d->pro_relu || d->pro_pool == 1 || d->out_f32 || d->drop_keep > 0.0f) return false;
+    if ((reinterpret_cast<uintptr_t>(d->d_C) & 15) || d->ldx % 8 || d->ldc % 8 || g.c_off % 8) return false;
+    if (d->d_R && ((reinterpret_cast<uintptr_t>(d->d_R) & 7) || d->ldr % 4)) return false;
+    return true;
+}
+
+int launch_conv256(const vc_gemm_desc* d, hipStream_t st) {
+    Conv256Args c;
+    const vc_gemm_group& g = d->groups[0];
+    c.X = d->d_X; c.M = d->M; c.T = d->T; c.Cin = d->Cin; c.ldx = d->ldx; c.N = d->N;
+    c.Bt = g.d_Bt; c.K = g.K; c.taps = g.taps; c.pad_l = g.pad_l; c.c_off = g.c_off;
+    c.pool = d->pro_pool != 0;
+    c.epi_scale = d->d_epi_scale; c.epi_shift = d->d_epi_shift; c.act = d->act;
+    c.R = d->d_R; c.ldr = d->ldr; c.C = d->d_C; c.ldc = d->ldc;
+    return vc_launch_conv256(c, st);
+}
+
 template <typename T> int launch(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
+    if (sizeof(T) == 2 && conv256_ok(d)) return launch_conv256(d, st);
     // convolution-specialised kernel: every group has taps in [2, 32] (a grouped bank launch may
     // include its k = 1 member) and Cin is a whole number of channel slabs
     bool conv_ok = d->mode == VC_GEMM_PLAIN && d->Cin % Tr<T>::BK == 0 && d->M >= 128;

@@ -110,6 +110,43 @@ def test_conv1d_banks(dtype, K, cin):
     _close(y, ref, TOL[dtype], 'banks K=%d' % K)
 
 
+@pytest.mark.parametrize('N,T,cin,f,size,pool,with_res', [(2, 400, 512, 128, 3, 2, False), (3, 100, 384, 256, 3, 0, True),
+                                                         (1, 333, 1024, 128, 1, 0, False), (5, 77, 256, 256, 5, 2, True)])
+def test_conv1d_deep_pipeline_kernel(N, T, cin, f, size, pool, with_res, monkeypatch):
+    """Long-K single-filter bf16 convolutions run on vc_conv256.hip (LDS-direct operand loads, the
+    max-pool taken on the fragments).  Bit-identical to conv_kernel / gemm_kernel and within the bf16
+    tolerance of the oracle; window edges (SAME padding, last frame pooling with itself) included."""
+    import modules
+    from conftest import poison_gpu_state
+    rng = np.random.RandomState(cin + T)
+    st = _store('bfloat16')
+    x = torch.from_numpy(np.abs(rng.standard_normal((N, T, cin))).astype(np.float32))
+    res = torch.from_numpy(rng.standard_normal((N, T, f)).astype(np.float32))
+    xd = modules.convert(x.cuda(), st.dtype)
+    rd = modules.convert(res.cuda(), st.dtype) if with_res else None
+    with modules.variable_store(st), modules.variable_scope('c'):
+        modules._bn_vars(st, 'c/p1', f)
+        for nm in ('beta', 'gamma', 'moving_mean', 'moving_variance'):
+            v = rng.uniform(0.5, 1.5, f) if nm in ('gamma', 'moving_variance') else rng.uniform(-0.3, 0.3, f)
+            st.assign('c/p1/' + nm, v.astype(np.float32))
+        kw = dict(filters=f, size=size, scope='p1', bn_scope='p1', activation_fn='relu', pool_input=pool, residual=rd)
+        monkeypatch.setenv('VC_CONV256', '0')
+        y_old = modules.conv1d(xd, **kw)
+        monkeypatch.setenv('VC_CONV256', '1')
+        poison_gpu_state()
+        y = modules.conv1d(xd, **kw)
+    torch.cuda.synchronize()
+    assert not torch.isnan(y.float()).any()
+    assert torch.equal(y, y_old)
+    w = {k: v.cpu().double() for k, v in st.vars.items()}
+    cast = lambda t: t.bfloat16().double()
+    xin = mo.max_pool_2_same(cast(x)) if pool else cast(x)
+    ref = torch.relu(mo.bn(mo.conv1d(xin, cast(st.vars['c/p1/conv1d/kernel'].cpu())), w, 'c/p1'))
+    if with_res:
+        ref = ref + cast(res)
+    _close(y, ref, TOL['bfloat16'], 'conv256 cin=%d' % cin)
+
+
 @pytest.mark.parametrize('N,T,cin,K', [(3, 100, 128, 32), (5, 333, 64, 8), (2, 400, 256, 32), (1, 256, 64, 2)])
 def test_conv1d_banks_paired_256_tile_kernel(N, T, cin, K, monkeypatch):
     """bf16 banks with >= 256 frames, 64-channel slabs and an even K run on vc_bank256.hip (filter
