@@ -215,7 +215,7 @@ def bench_full(args, rank, world):
             ms_bank = time_events(lambda: modules.conv1d_banks(pre, K=32, is_training=False), 20)
             bank = modules.conv1d_banks(pre, K=32, is_training=False)
             ms_p1 = time_events(lambda: modules.conv1d(bank, filters=256, size=3, scope="conv1d_1", bn_scope="conv1d_1",
-                                                       activation_fn='relu', pool_input=True), 20)
+                                                       activation_fn='relu', pool_input=2), 20)
             ms_gru = time_events(lambda: modules.gru(pre, num_units=256, bidirection=True), 5)
         fl_bank = 2.0 * 256 * 128 * 528 * W * T
         fl_p1 = 2.0 * 3 * 4096 * 256 * W * T
