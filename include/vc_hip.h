@@ -191,9 +191,16 @@ typedef struct vc_gemm_desc {
      * element index m*ldc + column; see drop_keep_elem in csrc/vc_gemm.hip). */
     float drop_keep;
     unsigned long long drop_seed;
+    int32_t epi_pool;              /* 1: store max(y[t], y[t+1]) inside each window of T frames (the last frame keeps
+                                    * its value) = tf.layers.max_pooling1d(2, 1, 'same') of the result, fused into the
+                                    * producer (modules.py:331 after :329).  Needs act = ReLU and a launch for which
+                                    * vc_conv_gemm_epi_pool_supported() returns 1; vc_conv_gemm rejects it otherwise. */
 } vc_gemm_desc;
 
 int vc_conv_gemm(const vc_gemm_desc* desc, void* stream);
+/* 1 if `desc` (with epi_pool set) can run with the pooled epilogue: the bf16 filter-bank launch that
+ * maps onto the paired 256-row tiles (tiles then overlap by one frame), else 0.  Host-only. */
+int vc_conv_gemm_epi_pool_supported(const vc_gemm_desc* desc);
 
 /* softmax + argmax over the last axis (encoder.py:110-111): logits float32 [M, ldl >= N] ->
  * probabilities (dtype out_dtype, row stride ldp, columns [N, ldp) zero-filled so the

@@ -50,7 +50,8 @@ class GemmDesc(C.Structure):
                 ('pro_relu', C.c_int32), ('pro_pool', C.c_int32),
                 ('d_epi_scale', C.c_void_p), ('d_epi_shift', C.c_void_p), ('act', C.c_int32),
                 ('d_R', C.c_void_p), ('ldr', C.c_int32), ('d_C', C.c_void_p), ('ldc', C.c_int32),
-                ('out_f32', C.c_int32), ('drop_keep', C.c_float), ('drop_seed', C.c_ulonglong)]
+                ('out_f32', C.c_int32), ('drop_keep', C.c_float), ('drop_seed', C.c_ulonglong),
+                ('epi_pool', C.c_int32)]
 
 
 class WgradGroup(C.Structure):
@@ -112,6 +113,7 @@ _SIGS = {
                                C.c_float, _P]),
     'vc_gru_train_forward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     'vc_gru_backward': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    'vc_conv_gemm_epi_pool_supported': (C.c_int, [C.POINTER(GemmDesc)]),
     'vc_gather_rows': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     'vc_vocoder_plan_create': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
     'vc_vocoder_plan_destroy': (None, [_P]),

@@ -52,7 +52,7 @@ bank256_kernel(Bank256Args a) {
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
     const int wr = wid >> 2, wc = wid & 3;             // wave tile: rows wr*128.., cols wc*64..
     const Bank256Pair pr = a.p[a.n_pairs - 1 - (int)blockIdx.y];   // widest pair first
-    const int m0 = blockIdx.x * BM;
+    const int m0 = blockIdx.x * (a.pool ? BM - 1 : BM);    // pooled output: tiles overlap by one frame
     const int ntap = pr.taps0 + 1;                     // taps of the wider filter
     const int nslab = a.Cin >> 6;
     const int ntiles = nslab * ntap;
@@ -295,14 +295,25 @@ bank256_kernel(Bank256Args a) {
     {
         const int l16 = tid & 15, hr = tid >> 4;           // 16 lanes x 16 B = one 128-channel half row
         __bf16* C = reinterpret_cast<__bf16*>(a.C);
+        const int nrows = a.pool ? BM - 1 : BM;
 #pragma unroll 4
         for (int pss = 0; pss < 16; ++pss) {
             const int h = pss * 32 + hr;                   // half-row index: row = h >> 1, half = h & 1
             const int row = h >> 1, half = h & 1;
             const int gm = m0 + row;
-            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(smem + row * EP + half * 256 + l16 * 16);
+            const char* src = smem + row * EP + half * 256 + l16 * 16;
+            bf16x8 vv = *reinterpret_cast<const bf16x8*>(src);
+            if (a.pool && row < BM - 1) {
+                // max_pooling1d(2, 1, 'same') of the post-ReLU result: u16 order == bf16 order for x >= 0;
+                // the window's last frame pools with itself
+                typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+                const bf16x8 nx = *reinterpret_cast<const bf16x8*>(src + EP);
+                const bf16x8 mx = __builtin_bit_cast(bf16x8, __builtin_elementwise_max(__builtin_bit_cast(u16x8, vv),
+                                                                                      __builtin_bit_cast(u16x8, nx)));
+                vv = (min(gm, a.M - 1) % a.T == a.T - 1) ? vv : mx;
+            }
             // streaming store: the 210 MB output must not displace the weight tiles from L2
-            if (gm < a.M && !(a.dbg & 2))
+            if (gm < a.M && row < nrows && !(a.dbg & 2))
                 __builtin_nontemporal_store(vv, reinterpret_cast<bf16x8*>(C + (size_t)gm * a.ldc + (half ? pr.c_off1 : pr.c_off0) + l16 * 8));
         }
     }
@@ -317,7 +328,8 @@ int vc_launch_bank256(const Bank256Args& a, hipStream_t st) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
         attr_done = true;
     }
-    hipLaunchKernelGGL(bank256_kernel, dim3((a.M + BM - 1) / BM, a.n_pairs), dim3(NT), LDS_BYTES, st, a);
+    const int stride = a.pool ? BM - 1 : BM;
+    hipLaunchKernelGGL(bank256_kernel, dim3((a.M + stride - 1) / stride, a.n_pairs), dim3(NT), LDS_BYTES, st, a);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }

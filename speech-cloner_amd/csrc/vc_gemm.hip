@@ -792,6 +792,7 @@ int launch_bank256(const vc_gemm_desc* d, hipStream_t st) {
     b.X = d->d_X; b.M = d->M; b.T = d->T; b.Cin = d->Cin; b.ldx = d->ldx;
     b.epi_scale = d->d_epi_scale; b.epi_shift = d->d_epi_shift; b.act = d->act;
     b.C = d->d_C; b.ldc = d->ldc; b.n_pairs = d->n_groups / 2;
+    b.pool = d->epi_pool != 0;
     for (int g = 0; g < d->n_groups; g += 2) {
         Bank256Pair& p = b.p[g / 2];
         p.Bt0 = d->groups[g].d_Bt; p.Bt1 = d->groups[g + 1].d_Bt;
@@ -886,8 +887,15 @@ extern "C" int vc_conv_gemm(const vc_gemm_desc* d, void* stream) {
         VC_REQUIRE(gg.c_off >= 0 && gg.c_off + d->N <= d->ldc || d->mode == VC_GEMM_HIGHWAY, "group %d: columns exceed ldc", g);
         ka.g[g].Bt = gg.d_Bt; ka.g[g].K = gg.K; ka.g[g].taps = gg.taps; ka.g[g].pad_l = gg.pad_l; ka.g[g].c_off = gg.c_off;
     }
+    if (d->epi_pool)
+        VC_REQUIRE(d->act == VC_ACT_RELU && bank256_ok(d),
+                   "epi_pool needs act = ReLU and a launch vc_conv_gemm_epi_pool_supported() accepts");
     hipStream_t st = static_cast<hipStream_t>(stream);
     return d->dtype == VC_F32 ? launch<float>(d, ka, st) : launch<__bf16>(d, ka, st);
+}
+
+extern "C" int vc_conv_gemm_epi_pool_supported(const vc_gemm_desc* d) {
+    return d != nullptr && d->act == VC_ACT_RELU && d->M > 0 && d->T > 0 && d->M % d->T == 0 && bank256_ok(d) ? 1 : 0;
 }
 
 extern "C" int vc_conv_wgrad(const vc_wgrad_desc* d, void* stream) {

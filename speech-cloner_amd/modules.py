@@ -177,11 +177,10 @@ def _as3(x):
     return x
 
 
-def gemm_launch(X, M, T, Cin, ldx, N, groups, Cout, ldc, vc_dtype, mode=_vc.GEMM_PLAIN,
-                pro_scale=None, pro_shift=None, pro_relu=0, pro_pool=0,
-                epi_scale=None, epi_shift=None, act=_vc.ACT_NONE, R=None, ldr=0, out_f32=False):
-    """Fill a vc_gemm_desc and launch vc_conv_gemm on the current stream.
-    groups: list of (Bt tensor [N, K], K, taps, pad_l, c_off)."""
+def gemm_desc(X, M, T, Cin, ldx, N, groups, Cout, ldc, vc_dtype, mode=_vc.GEMM_PLAIN,
+              pro_scale=None, pro_shift=None, pro_relu=0, pro_pool=0,
+              epi_scale=None, epi_shift=None, act=_vc.ACT_NONE, R=None, ldr=0, out_f32=False, epi_pool=0):
+    """Fill a vc_gemm_desc.  groups: list of (Bt tensor [N, K], K, taps, pad_l, c_off)."""
     d = _vc.GemmDesc()
     d.dtype, d.mode = vc_dtype, mode
     d.d_X = X.data_ptr()
@@ -198,6 +197,13 @@ def gemm_launch(X, M, T, Cin, ldx, N, groups, Cout, ldc, vc_dtype, mode=_vc.GEMM
     d.d_R = R.data_ptr() if R is not None else None
     d.ldr = ldr
     d.d_C, d.ldc, d.out_f32 = Cout.data_ptr(), ldc, int(bool(out_f32))
+    d.epi_pool = int(epi_pool)
+    return d
+
+
+def gemm_launch(X, M, T, Cin, ldx, N, groups, Cout, ldc, vc_dtype, **kw):
+    """Fill a vc_gemm_desc (see gemm_desc) and launch vc_conv_gemm on the current stream."""
+    d = gemm_desc(X, M, T, Cin, ldx, N, groups, Cout, ldc, vc_dtype, **kw)
     _vc.check(_vc.lib().vc_conv_gemm(C.byref(d), _vc.current_stream()))
     return Cout
 
@@ -364,9 +370,12 @@ def conv1d(inputs, filters=None, size=1, rate=1, padding="SAME", use_bias=False,
     return out
 
 
-def conv1d_banks(inputs, K=16, embed_size=256, is_training=True, scope="conv1d_banks", reuse=None):
+def conv1d_banks(inputs, K=16, embed_size=256, is_training=True, scope="conv1d_banks", reuse=None, pool_output=None):
     """modules.py:144-166: K convolutions of width 1..K (embed_size//2 filters each), concat,
-    batch norm, relu -- ONE grouped launch, heaviest bank first, norm+relu in the epilogue."""
+    batch norm, relu -- ONE grouped launch, heaviest bank first, norm+relu in the epilogue.
+    pool_output='auto' lets the launch also apply the max_pooling1d(2, 1, 'same') that follows the
+    banks in CBHG (modules.py:331) where the kernel supports it; the return value is then
+    (output, pooled: bool)."""
     if is_training:
         raise NotImplementedError(' - ERROR, conv1d_banks: training mode runs through the fused training step')
     torch = _torch()
@@ -385,9 +394,14 @@ def conv1d_banks(inputs, K=16, embed_size=256, is_training=True, scope="conv1d_b
             groups.append((bt, k * Cin, k, (k - 1) // 2, F_ * (k - 1)))
         s, sh = _prep_bn(store, _scope('bn'), F_ * K)
     out = torch.empty((N_, T_, F_ * K), dtype=store.dtype, device=x.device)
-    gemm_launch(x, N_ * T_, T_, Cin, Cin, F_, groups, out, F_ * K, store.vc_dtype,
-                epi_scale=s, epi_shift=sh, act=_vc.ACT_RELU)
-    return out
+    d = gemm_desc(x, N_ * T_, T_, Cin, Cin, F_, groups, out, F_ * K, store.vc_dtype,
+                  epi_scale=s, epi_shift=sh, act=_vc.ACT_RELU, epi_pool=1 if pool_output == 'auto' else 0)
+    pooled = False
+    if pool_output == 'auto':
+        pooled = bool(_vc.lib().vc_conv_gemm_epi_pool_supported(C.byref(d)))
+        d.epi_pool = int(pooled)
+    _vc.check(_vc.lib().vc_conv_gemm(C.byref(d), _vc.current_stream()))
+    return (out, pooled) if pool_output == 'auto' else out
 
 
 def gru(inputs, num_units=None, bidirection=False, scope="gru", use_Cudnn=False, reuse=None):
@@ -460,10 +474,11 @@ def CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dro
     if use_lstm:
         raise NotImplementedError(' - ERROR, CBHG: use_lstm is not used by any shipped configuration')
     with variable_scope(scope):
-        enc = conv1d_banks(inputs, K=num_conv_banks, is_training=is_training)              # (N, T, K*128)
-        # max pooling (modules.py:331) is fused into conv1d_1's operand load
+        # max pooling (modules.py:331) rides on the bank launch's stores where that kernel can do it,
+        # else on conv1d_1's operand load (2: operand is post-ReLU (>= 0), integer-ordered max)
+        enc, pooled = conv1d_banks(inputs, K=num_conv_banks, is_training=is_training, pool_output='auto')   # (N, T, K*128)
         enc = conv1d(enc, filters=embed_size // 2, size=3, scope="conv1d_1", bn_scope="conv1d_1",
-                     activation_fn='relu', pool_input=2)   # 2: operand is post-ReLU (>= 0)   (N, T, E/2)
+                     activation_fn='relu', pool_input=0 if pooled else 2)                  # (N, T, E/2)
         enc = conv1d(enc, filters=embed_size // 2, size=3, scope="conv1d_2", bn_scope="conv1d_2",
                      residual=inputs)                                                      # + residual
         for i in range(num_highwaynet_blocks):

@@ -219,6 +219,39 @@ def test_gru_bidirectional(dtype, H, T):
     _close(y, ref, 5e-5 if dtype == 'float32' else 3e-2, 'gru H=%d' % H)
 
 
+@pytest.mark.parametrize('N,T,cin,K', [(3, 100, 128, 32), (2, 400, 64, 4), (4, 255, 64, 2), (7, 64, 128, 6)])
+def test_conv1d_banks_pooled_output(N, T, cin, K):
+    """epi_pool: the bank launch stores max_pooling1d(2, 1, 'same') of its result (modules.py:331);
+    row tiles then overlap by one frame.  Exactly the pool of the unpooled launch, window ends and
+    tile seams (T = 255 puts every window end on a seam) included."""
+    import modules
+    rng = np.random.RandomState(K * T)
+    st = _store('bfloat16')
+    xd = modules.convert(torch.from_numpy(rng.standard_normal((N, T, cin)).astype(np.float32)).cuda(), st.dtype)
+    with modules.variable_store(st), modules.variable_scope('e'):
+        y = modules.conv1d_banks(xd, K=K, is_training=False)
+        yp, pooled = modules.conv1d_banks(xd, K=K, is_training=False, pool_output='auto')
+    torch.cuda.synchronize()
+    assert pooled == (N * T >= 256)
+    ref = torch.maximum(y.float(), torch.cat([y.float()[:, 1:], y.float()[:, -1:]], dim=1)) if pooled else y.float()
+    assert torch.equal(yp.float(), ref)
+
+
+def test_epi_pool_is_rejected_where_unsupported():
+    import ctypes as C
+    import _vc
+    import modules
+    st = _store('float32')
+    x = torch.zeros(2, 200, 64, device='cuda')
+    with modules.variable_store(st), modules.variable_scope('e'):
+        modules.conv1d_banks(x, K=4, is_training=False)
+        with pytest.raises(_vc.VCError, match='epi_pool'):
+            bt = st.cached(('conv', 'e/conv1d_banks/conv1d'), lambda: None)
+            out = torch.empty(2, 200, 128, device='cuda')
+            modules.gemm_launch(x, 400, 200, 64, 64, 128, [(bt, 64, 1, 0, 0)], out, 128, st.vc_dtype,
+                                act=_vc.ACT_RELU, epi_pool=1)
+
+
 @pytest.mark.parametrize('H,T,N', [(128, 60, 3), (256, 40, 35), (256, 24, 16), (128, 50, 33)])
 def test_gru_mfma_recurrence(H, T, N, monkeypatch):
     """The 16-sequences-per-workgroup MFMA recurrence (chosen by itself from 32 sequences up, forced
