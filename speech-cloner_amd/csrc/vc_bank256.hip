@@ -35,7 +35,8 @@ constexpr int BM = 256;
 constexpr int A_ROWS = 288;                        // 256 + 32 halo rows
 constexpr int A_BYTES = A_ROWS * 128;
 constexpr int B_BYTES = 256 * 128;
-constexpr int LDS_BYTES = 2 * A_BYTES + 2 * B_BYTES;   // 139,264
+constexpr int COEF_OFF = 2 * A_BYTES + 2 * B_BYTES;    // 139,264: scale[256] | shift[256] of the pair (f32)
+constexpr int LDS_BYTES = COEF_OFF + 2 * 256 * 4;
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)g,
@@ -162,6 +163,12 @@ bank256_kernel(Bank256Args a) {
     };
 
     // ---------------- prologue
+    {   // BatchNorm scale / shift of the pair's 256 channels -> LDS (read again only in the epilogue)
+        float* coef = reinterpret_cast<float*>(smem + COEF_OFF);
+        const int ch = tid & 255, oc = (ch < 128 ? pr.c_off0 : pr.c_off1) + (ch & 127);
+        const float* src = tid < 256 ? a.epi_scale : a.epi_shift;
+        coef[tid] = src ? src[oc] : (tid < 256 ? 1.0f : 0.0f);
+    }
     stageA(0, 0);
     stageB(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -264,15 +271,13 @@ bank256_kernel(Bank256Args a) {
     constexpr int EP = 528;                            // LDS row pitch of the [256][256] bf16 tile
     __syncthreads();                                   // all fragment reads retired; no load in flight
     {
-        const int c_off = left_wave ? pr.c_off0 : pr.c_off1;
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int chl = (wc & 1) * 64 + c * 32 + 8 * q + 4 * lh;       // channel within the filter
-                float4 sv = make_float4(1.0f, 1.0f, 1.0f, 1.0f), bv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                if (a.epi_scale) sv = *reinterpret_cast<const float4*>(a.epi_scale + c_off + chl);
-                if (a.epi_shift) bv = *reinterpret_cast<const float4*>(a.epi_shift + c_off + chl);
+                const int chp = wc * 64 + c * 32 + 8 * q + 4 * lh;             // channel within the pair
+                const float4 sv = *reinterpret_cast<const float4*>(smem + COEF_OFF + chp * 4);
+                const float4 bv = *reinterpret_cast<const float4*>(smem + COEF_OFF + 1024 + chp * 4);
                 const float svv[4] = {sv.x, sv.y, sv.z, sv.w}, bvv[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {

@@ -191,9 +191,23 @@ template <int MI> struct Mma<__bf16, MI> {
 // chunks of a row (a lane of the 32 x 32 MFMA result owns one column: storing straight from the
 // accumulators writes 2-byte elements 64 B apart per row, which costs more than the K loop of the
 // short-K dense layers).  smem: the kernel's operand buffers, free after the last barrier.
+// scale/shift of this lane's two output columns, fetched before the K loop (two dependent global
+// loads at epilogue time cost more than the whole K loop of a short-K dense layer)
+struct EpiCoef { float s[2], b[2]; };
+__device__ __forceinline__ EpiCoef epilogue_coef(const KArgs& a, const KGroup& grp, int n0, int wn, int lane) {
+    EpiCoef c;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int oc = grp.c_off + min(n0 + wn * 64 + ni * 32 + (lane & 31), a.N - 1);
+        c.s[ni] = a.epi_scale ? a.epi_scale[oc] : 1.0f;
+        c.b[ni] = a.epi_shift ? a.epi_shift[oc] : 0.0f;
+    }
+    return c;
+}
+
 template <typename T, int MI>
 __device__ __forceinline__ void epilogue_tile(const KArgs& a, const KGroup& grp, char* smem, const f32x16 (&acc)[MI][2],
-                                              int m0, int n0, int row_w, int wn, int lane, int tid) {
+                                              const EpiCoef& coef, int m0, int n0, int row_w, int wn, int lane, int tid) {
     constexpr int BM = 64 * MI;
     const bool f32o = a.out_f32 || sizeof(T) == 4;
     const int es = f32o ? 4 : 2;
@@ -204,8 +218,7 @@ __device__ __forceinline__ void epilogue_tile(const KArgs& a, const KGroup& grp,
         const int lcol = wn * 64 + ni * 32 + i;
         const int gn = min(n0 + lcol, a.N - 1);
         const int oc = grp.c_off + gn;
-        const float s = a.epi_scale ? a.epi_scale[oc] : 1.0f;
-        const float b = a.epi_shift ? a.epi_shift[oc] : 0.0f;
+        const float s = coef.s[ni], b = coef.b[ni];
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
@@ -359,6 +372,7 @@ gemm_kernel(KArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
+    const EpiCoef coef = (MODE == VC_GEMM_PLAIN) ? epilogue_coef(a, grp, n0, wn, lane) : EpiCoef{};
     gload();
     lstore(0);
     __syncthreads();
@@ -374,7 +388,7 @@ gemm_kernel(KArgs a) {
     // ---------------------------------------------------------------------------- epilogue
     const int i = lane & 31, h = lane >> 5;
     if (MODE == VC_GEMM_PLAIN) {
-        epilogue_tile<T, MI>(a, grp, smem, acc, m0, n0, wm * 32 * MI, wn, lane, tid);
+        epilogue_tile<T, MI>(a, grp, smem, acc, coef, m0, n0, wm * 32 * MI, wn, lane, tid);
     } else {
         // highway: columns come in (32 x dense1 | 32 x dense2) pairs; output unit index:
         const int hc = (n0 + wn * 64) / 2 + i;
@@ -533,6 +547,7 @@ conv_kernel(KArgs a) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
 
     const int nit = ncs * taps;
+    const EpiCoef coef = epilogue_coef(a, grp, n0, wn, lane);
     gloadA(0);
     gloadB(rbE);                                         // slab 0
     if (nit > 1) gloadB(rbO);                            // slab 1
@@ -599,7 +614,7 @@ conv_kernel(KArgs a) {
     }
 
     // ---------------------------------------------------------------------------- epilogue
-    epilogue_tile<T, MI>(a, grp, smem, acc, m0, n0, wm * 64, wn, lane, tid);
+    epilogue_tile<T, MI>(a, grp, smem, acc, coef, m0, n0, wm * 64, wn, lane, tid);
 }
 
 template <typename T, int PRO> int launch_conv(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
