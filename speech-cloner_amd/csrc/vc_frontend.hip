@@ -30,6 +30,7 @@ constexpr int FE_G3 = 32;         // frames per block, finalize
 constexpr int A_STRIDE = 17;      // LDS stride of one (g,k1) row of 16 complex values
 constexpr float NEG_INF = -3.402823466e38f;
 constexpr float POS_INF = 3.402823466e38f;
+constexpr int FE_STAT = 8;        // floats per tile record
 
 struct FeDev {
     const float* window;      // [n_fft]
@@ -51,7 +52,8 @@ struct FeArgs {
     float mfcc_norm, m_norm, p_norm;
     int32_t first_mfcc, deriv, clip;
     float* partial;           // [B][FE_NPART]
-    float* stats;             // [B][ntiles][4]  pmax pmin mmax mmin
+    float* stats;             // [B][ntiles][8]  pmax pmin mmax mmin sum|x| (of the tile's own samples) - - -
+    int32_t fused_abs;        // 1: the STFT kernel accumulates sum|x| itself (hop <= n_fft/2), 0: fe_abssum_kernel ran
     float* mel_raw;           // [B][max_frames][n_mels]
     float* mfcc;              // outputs
     float* mel_db;
@@ -91,13 +93,6 @@ fe_abssum_kernel(FeArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------ 2
-__device__ __forceinline__ float amp_scale(const FeArgs& a, int b, int L) {
-    if (a.amp_norm == 1.0f) return 1.0f;
-    float t = 0.0f;
-#pragma unroll
-    for (int c = 0; c < FE_NPART; ++c) t += a.partial[b * FE_NPART + c];
-    return a.amp_norm / (t / (float)L);
-}
 
 // Memory-level parallelism: every global-memory loop below issues U independent loads per thread
 // before it consumes the first one (a load -> use -> store loop keeps one load per wave in
@@ -121,12 +116,20 @@ __device__ __forceinline__ void copy_g2s(float* dst, const float* src, int n) {
     }
 }
 
-// Gather the samples a tile of frames needs into LDS: reflect padding of the pre-emphasised,
-// amplitude-normalised signal (np.pad(y_preem, n_fft//2, 'reflect') inside librosa.stft).
-__device__ __forceinline__ void load_tile(const FeArgs& a, int b, int L, int f0, float scale, float* xs) {
+// Gather the samples a tile of frames needs into LDS: reflect padding of the pre-emphasised signal
+// (np.pad(y_preem, n_fft//2, 'reflect') inside librosa.stft).  The amplitude normalisation
+// (audio_lib.py:125-126: y *= c, c = norm / mean|y|) is NOT applied here: the whole chain up to the
+// power spectrum is linear, so c becomes a dB offset that fe_finalize_kernel adds (20 log10 c on the
+// power dB, 40 log10 c on the mel dB, before the amin clamps).  That removes the dependency of this
+// kernel on a full pass over the utterance; instead it returns sum|x| over the samples of its own
+// frames [f0*hop, (f0+G)*hop) (requires hop <= n_fft/2, else fe_abssum_kernel runs).
+template <int G>
+__device__ __forceinline__ float load_tile(const FeArgs& a, int b, int L, int f0, float* xs) {
     const float* x = a.wav + (size_t)b * a.wav_stride;
     const int half = a.n_fft / 2;
     const int base = f0 * a.hop - half;
+    const int own_lo = f0 * a.hop, own_hi = min((f0 + G) * a.hop, L);
+    float asum = 0.0f;
     for (int i0 = 0; i0 < a.span; i0 += FE_THREADS * FE_U) {
         float cur[FE_U], prev[FE_U];
 #pragma unroll
@@ -145,47 +148,53 @@ __device__ __forceinline__ void load_tile(const FeArgs& a, int b, int L, int f0,
                 float v = 0.0f;
                 if (idx < L + half) {
                     const int j = idx < 0 ? -idx : (idx >= L ? 2 * (L - 1) - idx : idx);
-                    const float c = scale * cur[u];
-                    const float pv = (j > 0) ? scale * prev[u] : 0.0f;
+                    const float c = cur[u];
+                    const float pv = (j > 0) ? prev[u] : 0.0f;
                     v = (a.pre_emph != 0.0f) ? (c - a.pre_emph * pv) : c;
                 }
                 xs[i] = v;
+                if (idx >= own_lo && idx < own_hi) asum += fabsf(cur[u]);
             }
         }
     }
+    return asum;
 }
 
 // Power tile in LDS -> raw power dB (global), sparse mel -> raw mel dB (workspace), tile stats.
-template <int G>
+// CNB / CNM: compile-time bin / mel counts (0 = take them from the arguments).  The per-element
+// loops below index by division; with runtime divisors those divisions were most of the kernel's
+// instructions (the front-end kernels are issue-bound, not HBM-bound: DESIGN.md section 6).
+template <int G, int CNB, int CNM>
 __device__ __forceinline__ void power_epilogue(const FeArgs& a, int b, int f0, int F, const float* P,
                                                int pstride, const float* melw, const int32_t* mstart,
-                                               const int32_t* moff, float* red) {
+                                               const int32_t* moff, float* red, float asum) {
     const int tid = threadIdx.x;
     const int nvalid = min(G, F - f0);
+    const int n_bins = CNB ? CNB : a.n_bins, n_mels = CNM ? CNM : a.n_mels;
     float pmax = NEG_INF, pmin = POS_INF, mmax = NEG_INF, mmin = POS_INF;
     {
-        float* out = a.pow_db + ((size_t)b * a.max_frames + f0) * a.n_bins;
-        const int total = nvalid * a.n_bins;
+        float* out = a.pow_db + ((size_t)b * a.max_frames + f0) * n_bins;
+        const int total = nvalid * n_bins;
         for (int idx = tid; idx < total; idx += FE_THREADS) {
-            const int g = idx / a.n_bins, k = idx - g * a.n_bins;
-            const float db = db10(fmaxf(1e-10f, P[g * pstride + k]));
+            const int g = idx / n_bins, k = idx - g * n_bins;
+            const float db = db10(fmaxf(1e-30f, P[g * pstride + k]));   // amin clamp comes with the amplitude offset
             out[idx] = db;
             pmax = fmaxf(pmax, db);
             pmin = fminf(pmin, db);
         }
     }
     {
-        float* out = a.mel_raw + ((size_t)b * a.max_frames + f0) * a.n_mels;
-        const int total = nvalid * a.n_mels;
+        float* out = a.mel_raw + ((size_t)b * a.max_frames + f0) * n_mels;
+        const int total = nvalid * n_mels;
         for (int idx = tid; idx < total; idx += FE_THREADS) {
-            const int g = idx / a.n_mels, m = idx - g * a.n_mels;
+            const int g = idx / n_mels, m = idx - g * n_mels;
             const float* p = P + g * pstride + mstart[m];
             const int o = moff[m], cnt = moff[m + 1] - o;
             float acc = 0.0f;
             for (int j = 0; j < cnt; ++j) acc = fmaf(melw[o + j], p[j], acc);
             // amplitude_to_db applied to the mel POWER (audio_lib.py:172):
-            // 10 log10(max(1e-10, acc^2)) == 20 log10(max(1e-5, |acc|))
-            const float db = 2.0f * db10(fmaxf(1e-5f, fabsf(acc)));
+            // 10 log10(max(1e-10, acc^2)) == 20 log10(max(1e-5, |acc|)); clamp applied in fe_finalize_kernel
+            const float db = 2.0f * db10(fmaxf(1e-18f, fabsf(acc)));
             out[idx] = db;
             mmax = fmaxf(mmax, db);
             mmin = fminf(mmin, db);
@@ -193,24 +202,28 @@ __device__ __forceinline__ void power_epilogue(const FeArgs& a, int b, int f0, i
     }
     pmax = vc::wave_max(pmax); pmin = vc::wave_min(pmin);
     mmax = vc::wave_max(mmax); mmin = vc::wave_min(mmin);
+    asum = vc::wave_sum(asum);
     const int w = tid >> 6;
-    if ((tid & 63) == 0) { red[w * 4 + 0] = pmax; red[w * 4 + 1] = pmin; red[w * 4 + 2] = mmax; red[w * 4 + 3] = mmin; }
+    if ((tid & 63) == 0) {
+        red[w * 5 + 0] = pmax; red[w * 5 + 1] = pmin; red[w * 5 + 2] = mmax; red[w * 5 + 3] = mmin; red[w * 5 + 4] = asum;
+    }
     __syncthreads();
     if (tid == 0) {
 #pragma unroll
         for (int i = 1; i < FE_THREADS / vc::WAVE; ++i) {
-            pmax = fmaxf(pmax, red[i * 4 + 0]); pmin = fminf(pmin, red[i * 4 + 1]);
-            mmax = fmaxf(mmax, red[i * 4 + 2]); mmin = fminf(mmin, red[i * 4 + 3]);
+            pmax = fmaxf(pmax, red[i * 5 + 0]); pmin = fminf(pmin, red[i * 5 + 1]);
+            mmax = fmaxf(mmax, red[i * 5 + 2]); mmin = fminf(mmin, red[i * 5 + 3]);
+            asum += red[i * 5 + 4];
         }
-        float* s = a.stats + ((size_t)b * a.ntiles + blockIdx.x) * 4;
-        s[0] = pmax; s[1] = pmin; s[2] = mmax; s[3] = mmin;
+        float* s = a.stats + ((size_t)b * a.ntiles + blockIdx.x) * FE_STAT;
+        s[0] = pmax; s[1] = pmin; s[2] = mmax; s[3] = mmin; s[4] = asum;
     }
 }
 
 __device__ __forceinline__ void write_neutral_stats(const FeArgs& a, int b) {
     if (threadIdx.x == 0) {
-        float* s = a.stats + ((size_t)b * a.ntiles + blockIdx.x) * 4;
-        s[0] = NEG_INF; s[1] = POS_INF; s[2] = NEG_INF; s[3] = POS_INF;
+        float* s = a.stats + ((size_t)b * a.ntiles + blockIdx.x) * FE_STAT;
+        s[0] = NEG_INF; s[1] = POS_INF; s[2] = NEG_INF; s[3] = POS_INF; s[4] = 0.0f;
     }
 }
 
@@ -222,6 +235,7 @@ __device__ __forceinline__ void stage_mel(const FeArgs& a, float* melw, int32_t*
 }
 
 // 400-point path: 16 frames per block, 256 threads.
+template <int CNM>
 __global__ void __launch_bounds__(FE_THREADS)
 fe_power400_kernel(FeArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -244,8 +258,7 @@ fe_power400_kernel(FeArgs a) {
     const int f0 = blockIdx.x * G;
     if (f0 >= F) { write_neutral_stats(a, b); return; }
 
-    const float scale = amp_scale(a, b, L);
-    load_tile(a, b, L, f0, scale, xs);
+    const float asum = load_tile<G>(a, b, L, f0, xs);
     copy_g2s(win, a.t.window, 816);                     // window[400] | tw400[416] are adjacent in both
     stage_mel(a, melw, mstart, moff);
     __syncthreads();
@@ -281,7 +294,7 @@ fe_power400_kernel(FeArgs a) {
         }
     }
     __syncthreads();
-    power_epilogue<G>(a, b, f0, F, P, 201, melw, mstart, moff, red);
+    power_epilogue<G, 201, CNM>(a, b, f0, F, P, 201, melw, mstart, moff, red, asum);
 }
 
 // Generic path (any n_fft): direct DFT from an LDS twiddle table.  O(n_fft^2) per frame; kept
@@ -307,8 +320,7 @@ fe_power_generic_kernel(FeArgs a) {
     const int f0 = blockIdx.x * G;
     if (f0 >= F) { write_neutral_stats(a, b); return; }
 
-    const float scale = amp_scale(a, b, L);
-    load_tile(a, b, L, f0, scale, xs);
+    const float asum = load_tile<G>(a, b, L, f0, xs);
     copy_g2s(win, a.t.window, N);
     copy_g2s(twc, a.t.twg, 2 * N);                      // cos | -sin
     stage_mel(a, melw, mstart, moff);
@@ -329,15 +341,16 @@ fe_power_generic_kernel(FeArgs a) {
         P[idx] = re * re + im * im;
     }
     __syncthreads();
-    power_epilogue<G>(a, b, f0, F, P, NB, melw, mstart, moff, red);
+    power_epilogue<G, 0, 0>(a, b, f0, F, P, NB, melw, mstart, moff, red, asum);
 }
 
 // ------------------------------------------------------------------------------------------ 3
+template <int CNM, int CNC, int CNB>
 __global__ void __launch_bounds__(FE_THREADS)
 fe_finalize_kernel(FeArgs a, int g2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int G = FE_G3;
-    const int NM = a.n_mels, NC = a.n_mfcc;
+    const int NM = CNM ? CNM : a.n_mels, NC = CNC ? CNC : a.n_mfcc, NB = CNB ? CNB : a.n_bins;
     const int NM4 = (NM + 3) & ~3;                     // rows padded to float4 (pad = 0)
     const int DS = NM4 + 4;                            // basis pitch: 16-B aligned, b128 conflict-free
     float* D = reinterpret_cast<float*>(smem);         // [NC][DS]
@@ -357,28 +370,39 @@ fe_finalize_kernel(FeArgs a, int g2) {
         const int nrows = min(G, a.max_frames - f0);
         float* o1 = a.mfcc + (row0 + f0) * mw;
         float* o2 = a.mel_db + (row0 + f0) * NM;
-        float* o3 = a.pow_db + (row0 + f0) * a.n_bins;
+        float* o3 = a.pow_db + (row0 + f0) * NB;
         for (int i = tid; i < nrows * mw; i += FE_THREADS) o1[i] = 0.0f;
         for (int i = tid; i < nrows * NM; i += FE_THREADS) o2[i] = 0.0f;
-        for (int i = tid; i < nrows * a.n_bins; i += FE_THREADS) o3[i] = 0.0f;
+        for (int i = tid; i < nrows * NB; i += FE_THREADS) o3[i] = 0.0f;
         return;
     }
 
     // per-utterance max/min from kernel 2's tile partials (wave 0)
     if (tid < vc::WAVE) {
         const int nt = (F + g2 - 1) / g2;
-        float pmax = NEG_INF, pmin = POS_INF, mmax = NEG_INF, mmin = POS_INF;
+        float pmax = NEG_INF, pmin = POS_INF, mmax = NEG_INF, mmin = POS_INF, asum = 0.0f;
         for (int t = tid; t < nt; t += vc::WAVE) {
-            const float* s = a.stats + ((size_t)b * a.ntiles + t) * 4;
+            const float* s = a.stats + ((size_t)b * a.ntiles + t) * FE_STAT;
             pmax = fmaxf(pmax, s[0]); pmin = fminf(pmin, s[1]);
             mmax = fmaxf(mmax, s[2]); mmin = fminf(mmin, s[3]);
+            asum += s[4];
         }
+        if (!a.fused_abs) asum = tid < FE_NPART ? a.partial[b * FE_NPART + tid] : 0.0f;
         pmax = vc::wave_max(pmax); pmin = vc::wave_min(pmin);
         mmax = vc::wave_max(mmax); mmin = vc::wave_min(mmin);
+        asum = vc::wave_sum(asum);
         if (tid == 0) {
-            const float pfloor = pmax - 80.0f, mfloor = mmax - 80.0f;   // top_db = 80
+            // amplitude normalisation as dB offsets (see load_tile): c = norm / mean|x|
+            float offp = 0.0f;
+            if (a.amp_norm != 1.0f) { const float c = a.amp_norm / (asum / (float)L); offp = 2.0f * db10(c); }
+            const float offm = 2.0f * offp;
+            // amin clamps of power_to_db / amplitude_to_db: 10 log10(1e-10) = 20 log10(1e-5) = -100 dB
+            pmax = fmaxf(pmax + offp, -100.0f); pmin = fmaxf(pmin + offp, -100.0f);
+            mmax = fmaxf(mmax + offm, -100.0f); mmin = fmaxf(mmin + offm, -100.0f);
+            const float pfloor = fmaxf(pmax - 80.0f, -100.0f), mfloor = fmaxf(mmax - 80.0f, -100.0f);   // top_db = 80
             sc[0] = pfloor; sc[1] = fmaxf(pmin, pfloor);                // floor, min after clip
             sc[2] = mfloor; sc[3] = fmaxf(mmin, mfloor);
+            sc[4] = offp; sc[5] = offm;
         }
     }
     for (int base = 0; base < NC * DS; base += FE_THREADS * FE_U) {
@@ -396,14 +420,14 @@ fe_finalize_kernel(FeArgs a, int g2) {
         }
     }
     __syncthreads();
-    const float pfloor = sc[0], pmin_c = sc[1], mfloor = sc[2], mmin_c = sc[3];
+    const float pfloor = sc[0], pmin_c = sc[1], mfloor = sc[2], mmin_c = sc[3], offp = sc[4], offm = sc[5];
     const int nvalid = min(G, F - f0);
     const int nrows = min(G, a.max_frames - f0);
 
     // power dB: top_db clip, min shift, scale, clip -- in place (audio_lib.py:157,230-231,239)
     {
-        float* o = a.pow_db + (row0 + f0) * a.n_bins;
-        const int tv = nvalid * a.n_bins, tr = nrows * a.n_bins;
+        float* o = a.pow_db + (row0 + f0) * NB;
+        const int tv = nvalid * NB, tr = nrows * NB;
         for (int base = 0; base < tr; base += FE_THREADS * FE_U) {
             float v[FE_U];
 #pragma unroll
@@ -414,7 +438,7 @@ fe_finalize_kernel(FeArgs a, int g2) {
                 if (i < tr) {
                     float w = 0.0f;
                     if (i < tv) {
-                        w = fmaxf(v[u], pfloor);
+                        w = fmaxf(v[u] + offp, pfloor);
                         if (a.p_norm != 1.0f) w = a.p_norm * (w - pmin_c);
                         if (a.clip) w = fminf(fmaxf(w, -1.0f), 1.0f);
                     }
@@ -442,14 +466,14 @@ fe_finalize_kernel(FeArgs a, int g2) {
                 if (i < tot) {
                     const int r = i / NM4, c = i - r * NM4;
                     const int f = f0 - 1 + r;
-                    Mc[i] = (c < NM && f >= 0 && f < F) ? fmaxf(v[u], mfloor) : 0.0f;
+                    Mc[i] = (c < NM && f >= 0 && f < F) ? fmaxf(v[u] + offm, mfloor) : 0.0f;
                 }
             }
         }
     }
     // frame 0's clipped mel row: its first cepstral coefficient is subtracted from every frame
     // (audio_lib.py:221)
-    for (int j = tid; j < NM4; j += FE_THREADS) M0[j] = j < NM ? fmaxf(a.mel_raw[row0 * NM + j], mfloor) : 0.0f;
+    for (int j = tid; j < NM4; j += FE_THREADS) M0[j] = j < NM ? fmaxf(a.mel_raw[row0 * NM + j] + offm, mfloor) : 0.0f;
     __syncthreads();
     {
         float* o = a.mel_db + (row0 + f0) * NM;
@@ -499,7 +523,7 @@ fe_finalize_kernel(FeArgs a, int g2) {
         float* o = a.mfcc + (row0 + f0) * mw;
         const int tr = nrows * mw;
         for (int i = tid; i < tr; i += FE_THREADS) {
-            const int g = i / mw, c = i - g * mw;
+            const int g = a.deriv ? i / (2 * NC) : i / NC, c = i - g * mw;      // constant divisors when CNC != 0
             const int f = f0 + g;
             float v = 0.0f;
             if (f < F) {
@@ -701,7 +725,7 @@ static void ws_layout(const vc_frontend_plan* p, int32_t batch, int32_t max_samp
     const int nt = (mf + g - 1) / g;
     size_t o = 0;
     *o_partial = o; o = align256(o + (size_t)batch * FE_NPART * 4);
-    *o_stats = o;   o = align256(o + (size_t)batch * nt * 4 * 4);
+    *o_stats = o;   o = align256(o + (size_t)batch * nt * 8 * 4);
     *o_mel = o;     o = align256(o + (size_t)batch * mf * p->cfg.n_mels * 4);
     *total = o; *ntiles = nt; *max_frames = mf;
 }
@@ -743,16 +767,18 @@ int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, con
     a.span = c.hop_length * (G - 1) + c.n_fft;
     hipStream_t st = static_cast<hipStream_t>(stream);
 
-    if ((stage_mask & 1) && c.mean_abs_amp_norm != 1.0f)
+    a.fused_abs = c.hop_length <= c.n_fft / 2;
+    if ((stage_mask & 1) && a.amp_norm != 1.0f && !a.fused_abs)
         hipLaunchKernelGGL(fe_abssum_kernel, dim3(FE_NPART, batch), dim3(FE_THREADS), 0, st, a);
 
     const size_t span_pad = ((size_t)a.span + 3) & ~(size_t)3;
-    const size_t mel_lds = (size_t)plan->nnz * 4 + ((size_t)c.n_mels * 2 + 1) * 4 + 16 * 4;
+    const size_t mel_lds = (size_t)plan->nnz * 4 + ((size_t)c.n_mels * 2 + 1) * 4 + 32 * 4;
     if (!(stage_mask & 2)) {
     } else if (plan->fft400) {
         const size_t lds = (span_pad + 400 + 416 + 2 * (size_t)FE_G400 * 13 * A_STRIDE + FE_G400 * 201 + 1) * 4 + mel_lds;
         VC_REQUIRE(lds <= 160 * 1024, "hop_length too large for the 400-point kernel's LDS tile (%zu B)", lds);
-        hipLaunchKernelGGL(fe_power400_kernel, dim3(ntiles, batch), dim3(FE_THREADS), lds, st, a);
+        if (a.n_mels == 80) hipLaunchKernelGGL(fe_power400_kernel<80>, dim3(ntiles, batch), dim3(FE_THREADS), lds, st, a);
+        else hipLaunchKernelGGL(fe_power400_kernel<0>, dim3(ntiles, batch), dim3(FE_THREADS), lds, st, a);
     } else {
         const size_t lds = (span_pad + 3 * (size_t)c.n_fft + (size_t)FE_GGEN * plan->n_bins) * 4 + mel_lds;
         VC_REQUIRE(lds <= 160 * 1024, "n_fft/hop_length too large for the generic kernel's LDS tile (%zu B)", lds);
@@ -766,7 +792,9 @@ int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, con
         const size_t nm4 = ((size_t)c.n_mels + 3) & ~(size_t)3;
         const size_t lds = ((size_t)c.n_mfcc * (nm4 + 4) + (size_t)(FE_G3 + 2) * (nm4 + c.n_mfcc) + 4 + nm4 + 8) * 4;
         VC_REQUIRE(lds <= 160 * 1024, "n_mels/n_mfcc too large for the finalize kernel's LDS tile (%zu B)", lds);
-        hipLaunchKernelGGL(fe_finalize_kernel, dim3(nt3, batch), dim3(FE_THREADS), lds, st, a, G);
+        if (a.n_mels == 80 && a.n_mfcc == 40 && a.n_bins == 201)
+            hipLaunchKernelGGL((fe_finalize_kernel<80, 40, 201>), dim3(nt3, batch), dim3(FE_THREADS), lds, st, a, G);
+        else hipLaunchKernelGGL((fe_finalize_kernel<0, 0, 0>), dim3(nt3, batch), dim3(FE_THREADS), lds, st, a, G);
     }
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
