@@ -105,16 +105,17 @@ size_t vc_frontend_workspace_bytes(const vc_frontend_plan* plan, int32_t batch, 
  *   d_pow_db   float32 [batch, max_frames, 1 + n_fft/2]
  *              rows f >= 1 + lens[b]/hop of utterance b are zero-filled.
  *   d_workspace / workspace_bytes: scratch of at least vc_frontend_workspace_bytes().
- * Three launches on `stream`: per-utterance |x| partial sums; STFT power + mel + dB with
- * per-tile max/min partials; finalize (top_db clip, min shift, DCT, delta, clip). */
+ * Two launches on `stream`: STFT power + mel + raw dB with per-tile max / min / sum|x| partials;
+ * finalize (amplitude normalisation as a dB offset, amin and top_db clips, min shift, DCT, delta,
+ * clip).  With hop_length > n_fft/2 a third launch computes the per-utterance sum|x| first. */
 int vc_frontend_f32(const vc_frontend_plan* plan, const float* d_wav, const int32_t* d_lens,
                     int32_t batch, int32_t max_samples, int32_t wav_stride,
                     float* d_mfcc, float* d_mel_db, float* d_pow_db,
                     void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Same call restricted to a subset of its launches (measurement hook used by bench.py to time
- * one kernel with HIP events): stage_mask bit0 = |x| partial sums, bit1 = STFT power/mel/dB,
- * bit2 = finalize.  Later stages read what earlier ones left in the workspace. */
+ * one kernel with HIP events): stage_mask bit0 = |x| partial sums (a launch only when
+ * hop_length > n_fft/2), bit1 = STFT power/mel/dB, bit2 = finalize.  Later stages read what earlier ones left in the workspace. */
 int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, const int32_t* d_lens,
                            int32_t batch, int32_t max_samples, int32_t wav_stride,
                            float* d_mfcc, float* d_mel_db, float* d_pow_db,
