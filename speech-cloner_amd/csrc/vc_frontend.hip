@@ -53,6 +53,7 @@ struct FeArgs {
     int32_t first_mfcc, deriv, clip;
     float* partial;           // [B][FE_NPART]
     float* stats;             // [B][ntiles][8]  pmax pmin mmax mmin sum|x| (of the tile's own samples) - - -
+    int32_t lds_alias;        // 400-point kernel: power tile and mel tables reuse the (g,k1) row buffers
     int32_t fused_abs;        // 1: the STFT kernel accumulates sum|x| itself (hop <= n_fft/2), 0: fe_abssum_kernel ran
     float* mel_raw;           // [B][max_frames][n_mels]
     float* mfcc;              // outputs
@@ -246,8 +247,12 @@ fe_power400_kernel(FeArgs a) {
     float* tw = win + 400;                             // [2][208]
     float* Are = tw + 416;                             // [NROW*17]
     float* Aim = Are + NROW * A_STRIDE;
-    float* P = Aim + NROW * A_STRIDE;                  // [G][201]
-    float* melw = P + G * 201 + 1;
+    // lds_alias (mel tables small enough to ride in registers meanwhile): the power tile takes over
+    // Are and the mel tables Aim once step 3 has consumed them -> 38 KB instead of 53 KB of LDS, four
+    // resident blocks per CU instead of three (the kernel is occupancy-, not HBM-bound)
+    const bool alias = a.lds_alias != 0;
+    float* P = alias ? Are : Aim + NROW * A_STRIDE;    // [G][201]
+    float* melw = alias ? Aim : P + G * 201 + 1;
     int32_t* mstart = reinterpret_cast<int32_t*>(melw + a.nnz);
     int32_t* moff = mstart + a.n_mels;
     float* red = reinterpret_cast<float*>(moff + a.n_mels + 1);
@@ -260,7 +265,16 @@ fe_power400_kernel(FeArgs a) {
 
     const float asum = load_tile<G>(a, b, L, f0, xs);
     copy_g2s(win, a.t.window, 816);                     // window[400] | tw400[416] are adjacent in both
-    stage_mel(a, melw, mstart, moff);
+    float mreg[4], treg[2];
+    const int ntab = 2 * a.n_mels + 1;
+    if (alias) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) mreg[u] = a.t.mel_w[min(tid + FE_THREADS * u, a.nnz - 1)];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) treg[u] = reinterpret_cast<const float*>(a.t.mel_start)[min(tid + FE_THREADS * u, ntab - 1)];
+    } else {
+        stage_mel(a, melw, mstart, moff);
+    }
     __syncthreads();
 
     // step 1+2: thread (g, n2): real 25-point DFT over n1 of the windowed samples, twiddle
@@ -281,17 +295,27 @@ fe_power400_kernel(FeArgs a) {
     }
     __syncthreads();
     // step 3: thread (g, k1): complex 16-point DFT over n2 -> |Y|^2 into the power tile
+    const int g3 = tid / 13, k13 = tid - g3 * 13;
+    float yr[16], yi[16];
     if (tid < NROW) {
-        const int g = tid / 13, k1 = tid - g * 13;
-        float zr[16], zi[16], yr[16], yi[16];
+        float zr[16], zi[16];
 #pragma unroll
         for (int n2 = 0; n2 < 16; ++n2) { zr[n2] = Are[A_STRIDE * tid + n2]; zi[n2] = Aim[A_STRIDE * tid + n2]; }
         vcfe::cdft16(zr, zi, yr, yi);
+    }
+    if (alias) __syncthreads();                         // every row is in registers before its buffer is reused
+    if (tid < NROW) {
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) {
-            const int bin = vcfe::bin_of(k1, k2);
-            if (bin >= 0) P[g * 201 + bin] = yr[k2] * yr[k2] + yi[k2] * yi[k2];
+            const int bin = vcfe::bin_of(k13, k2);
+            if (bin >= 0) P[g3 * 201 + bin] = yr[k2] * yr[k2] + yi[k2] * yi[k2];
         }
+    }
+    if (alias) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) if (tid + FE_THREADS * u < a.nnz) melw[tid + FE_THREADS * u] = mreg[u];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) if (tid + FE_THREADS * u < ntab) reinterpret_cast<float*>(mstart)[tid + FE_THREADS * u] = treg[u];
     }
     __syncthreads();
     power_epilogue<G, 201, CNM>(a, b, f0, F, P, 201, melw, mstart, moff, red, asum);
@@ -775,7 +799,11 @@ int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, con
     const size_t mel_lds = (size_t)plan->nnz * 4 + ((size_t)c.n_mels * 2 + 1) * 4 + 32 * 4;
     if (!(stage_mask & 2)) {
     } else if (plan->fft400) {
-        const size_t lds = (span_pad + 400 + 416 + 2 * (size_t)FE_G400 * 13 * A_STRIDE + FE_G400 * 201 + 1) * 4 + mel_lds;
+        // mel tables ride in registers (4 + 2 words per thread) while the row buffers are live
+        a.lds_alias = plan->nnz <= 4 * FE_THREADS && 2 * c.n_mels + 1 <= 2 * FE_THREADS &&
+                      (size_t)plan->nnz + 2 * c.n_mels + 1 + 32 <= (size_t)FE_G400 * 13 * A_STRIDE;
+        const size_t lds = a.lds_alias ? (span_pad + 400 + 416 + 2 * (size_t)FE_G400 * 13 * A_STRIDE) * 4
+                                       : (span_pad + 400 + 416 + 2 * (size_t)FE_G400 * 13 * A_STRIDE + FE_G400 * 201 + 1) * 4 + mel_lds;
         VC_REQUIRE(lds <= 160 * 1024, "hop_length too large for the 400-point kernel's LDS tile (%zu B)", lds);
         if (a.n_mels == 80) hipLaunchKernelGGL(fe_power400_kernel<80>, dim3(ntiles, batch), dim3(FE_THREADS), lds, st, a);
         else hipLaunchKernelGGL(fe_power400_kernel<0>, dim3(ntiles, batch), dim3(FE_THREADS), lds, st, a);
