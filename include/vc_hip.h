@@ -357,6 +357,18 @@ int vc_inv_preemphasis_normalize(const vc_vocoder_plan* plan, float* d_wav, cons
                                  int32_t max_frames, int32_t wav_stride, float coeff, float mean_abs_amp_norm,
                                  void* stream);
 
+/* ---- highway chain (modules.py:297-319 applied L times, modules.py:342-345) ------------------
+ * All L highwaynet layers of a CBHG block in one launch (bf16, H = 128 or 256): a block keeps its
+ * 128 frames in LDS across the layers, weights stream from L2 in MFMA fragment order.
+ * vc_highway_pack: d_Bt = the paired [2H, H] bf16 matrix of vc_conv_gemm's VC_GEMM_HIGHWAY mode
+ * (rows 64q..64q+31 = dense1 columns of units 32q.., rows 64q+32.. = dense2) -> d_packed [2H*H] bf16.
+ * vc_highway_chain: d_packed / d_bias are HOST arrays of n_layers (<= 8) device pointers
+ * (bias: float32 [2H] in the same paired order).  Results are bit-identical to n_layers launches of
+ * vc_conv_gemm(VC_GEMM_HIGHWAY).  d_Y may equal d_X. */
+int vc_highway_pack(const void* d_Bt, int32_t H, void* d_packed, void* stream);
+int vc_highway_chain(const void* d_X, int32_t M, int32_t H, int32_t ldx, int32_t n_layers,
+                     const void* const* d_packed, const float* const* d_bias, void* d_Y, int32_t ldy, void* stream);
+
 /* ---- on-device feature cache -----------------------------------
  * dst[r, :] = src[index[r], :] for index[r] >= 0, else pad_row (zeros when d_pad_row is NULL).
  * Rows are row_bytes wide (multiple of 4).  Replaces the h5py slicing + np.array stacking of

@@ -36,6 +36,16 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+// highwaynet gate (modules.py:315-319): relu(h) * t + x * (1 - t), t = sigmoid(tpre), written as
+// x + t * (relu(h) - x) with v_exp_f32 / v_rcp_f32 (1 ulp each) -- the gate arithmetic, not the
+// matrix work, bounds the fused highway chain, and an IEEE division costs ~10 instructions.
+// gemm_kernel's highway epilogue and highway_chain_kernel share it (bit-identical paths).
+__device__ __forceinline__ float highway_gate(float hpre, float tpre, float x) {
+    const float hv = fmaxf(hpre, 0.0f);
+    const float e = __builtin_amdgcn_exp2f(tpre * -1.4426950408889634f);
+    const float tv = __builtin_amdgcn_rcpf(1.0f + e);
+    return fmaf(tv, hv - x, x);
+}
 __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));

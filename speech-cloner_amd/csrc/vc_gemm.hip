@@ -403,10 +403,8 @@ gemm_kernel(KArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     const int gm = m0 + wm * 32 * MI + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (gm >= a.M) continue;
-                    const float hv = fmaxf(acc[mi][0][r] + bH, 0.0f);
-                    const float tv = 1.0f / (1.0f + __expf(-(acc[mi][1][r] + bT)));
                     const float xv = to_f32(X[(size_t)gm * a.ldx + hc]);
-                    store_out<T>(a.C, (size_t)gm * a.ldc + hc, hv * tv + xv * (1.0f - tv), a.out_f32);
+                    store_out<T>(a.C, (size_t)gm * a.ldc + hc, vc::highway_gate(acc[mi][0][r] + bH, acc[mi][1][r] + bT, xv), a.out_f32);
                 }
             }
         }

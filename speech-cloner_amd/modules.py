@@ -17,6 +17,7 @@ and cached; ``VariableStore.invalidate()`` drops them after a weight update.
 ``use_lstm`` true, which no shipped configuration sets -> ``CBHG(use_lstm=True)`` raises.
 """
 import contextlib
+import os
 import ctypes as C
 import math
 import threading
@@ -468,6 +469,41 @@ def highwaynet(inputs, num_units=None, scope="highwaynet", reuse=None):
     return out
 
 
+def highway_chain(inputs, num_units, n_layers, scope_fmt='highwaynet_{}'):
+    """n_layers consecutive highwaynet blocks (modules.py:342-345).  bf16 with 128 or 256 units and at
+    least 128 frames runs as ONE launch that keeps the activations on chip (vc_highway_chain);
+    anything else is the per-layer launch.  Same results either way (bit-identical)."""
+    torch = _torch()
+    store = _store()
+    x = _as3(inputs)
+    N_, T_, Cx = x.shape
+    fused = (store.dtype == torch.bfloat16 and Cx == num_units and Cx in (128, 256) and N_ * T_ >= 128
+             and 1 <= n_layers <= 8 and os.environ.get('VC_HIGHWAY_CHAIN', '1') != '0')
+    if not fused:
+        out = x
+        for i in range(n_layers):
+            out = highwaynet(out, num_units=num_units, scope=scope_fmt.format(i))
+        return out
+    packed, biases = [], []
+    for i in range(n_layers):
+        sc = _scope(scope_fmt.format(i))
+        bt, bias = _prep_highway(store, sc, Cx)
+
+        def build(bt=bt):
+            pk = torch.empty(bt.numel(), dtype=store.dtype, device=store.device)
+            _vc.check(_vc.lib().vc_highway_pack(bt.data_ptr(), Cx, pk.data_ptr(), _vc.current_stream()))
+            return pk
+        packed.append(store.cached(('highway_pk', sc), build))
+        biases.append(bias)
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    PA = (C.c_void_p * n_layers)(*[p.data_ptr() for p in packed])
+    BA = (C.c_void_p * n_layers)(*[b.data_ptr() for b in biases])
+    _vc.check(_vc.lib().vc_highway_chain(x.data_ptr(), N_ * T_, Cx, Cx, n_layers, PA, BA, out.data_ptr(), Cx,
+                                         _vc.current_stream()))
+    return out
+
+
 def CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dropout_rate=0.5, is_training=True,
          scope="CBHG", use_Cudnn=False, use_lstm=False, reuse=None):
     """modules.py:323-356.  [N, T, E/2] -> [N, T, E]."""
@@ -481,8 +517,7 @@ def CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dro
                      activation_fn='relu', pool_input=0 if pooled else 2)                  # (N, T, E/2)
         enc = conv1d(enc, filters=embed_size // 2, size=3, scope="conv1d_2", bn_scope="conv1d_2",
                      residual=inputs)                                                      # + residual
-        for i in range(num_highwaynet_blocks):
-            enc = highwaynet(enc, num_units=embed_size // 2, scope='highwaynet_{}'.format(i))
+        enc = highway_chain(enc, embed_size // 2, num_highwaynet_blocks)
         output = gru(enc, num_units=embed_size // 2, bidirection=True, use_Cudnn=use_Cudnn)  # (N, T, E)
     return output
 

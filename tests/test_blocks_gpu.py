@@ -252,6 +252,37 @@ def test_epi_pool_is_rejected_where_unsupported():
                                 act=_vc.ACT_RELU, epi_pool=1)
 
 
+@pytest.mark.parametrize('N,T,H,L', [(2, 400, 256, 6), (3, 100, 128, 4), (5, 77, 256, 3), (1, 128, 128, 1), (2, 333, 256, 8)])
+def test_highway_chain_single_launch(N, T, H, L, monkeypatch):
+    """All highwaynet layers of a CBHG block in one launch (activations stay in LDS between layers):
+    bit-identical to the per-layer launches, layer by layer within the bf16 tolerance of the oracle."""
+    import modules
+    from conftest import poison_gpu_state
+    rng = np.random.RandomState(H + L)
+    st = _store('bfloat16')
+    x = torch.from_numpy(rng.standard_normal((N, T, H)).astype(np.float32))
+    xd = modules.convert(x.cuda(), st.dtype)
+    with modules.variable_store(st), modules.variable_scope('h'):
+        monkeypatch.setenv('VC_HIGHWAY_CHAIN', '0')
+        modules.highway_chain(xd, H, L)
+        for i in range(L):
+            st.assign('h/highwaynet_%d/dense1/bias' % i, rng.uniform(-0.2, 0.2, H).astype(np.float32))
+            st.assign('h/highwaynet_%d/dense2/bias' % i, rng.uniform(-1.2, 0.2, H).astype(np.float32))
+        y_ref = modules.highway_chain(xd, H, L)
+        monkeypatch.setenv('VC_HIGHWAY_CHAIN', '1')
+        poison_gpu_state()
+        y = modules.highway_chain(xd, H, L)
+    torch.cuda.synchronize()
+    assert not torch.isnan(y.float()).any()
+    assert torch.equal(y, y_ref)
+    cast = lambda t: t.float().bfloat16().double()
+    w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
+    ref = cast(x)
+    for i in range(L):
+        ref = cast(mo.highwaynet(ref, w, 'h/highwaynet_%d' % i))           # the layers exchange bf16 activations
+    _close(y, ref, TOL['bfloat16'], 'highway chain H=%d L=%d' % (H, L))
+
+
 @pytest.mark.parametrize('H,T,N', [(128, 60, 3), (256, 40, 35), (256, 24, 16), (128, 50, 33)])
 def test_gru_mfma_recurrence(H, T, N, monkeypatch):
     """The 16-sequences-per-workgroup MFMA recurrence (chosen by itself from 32 sequences up, forced
