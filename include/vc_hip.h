@@ -359,15 +359,21 @@ int vc_inv_preemphasis_normalize(const vc_vocoder_plan* plan, float* d_wav, cons
 
 /* ---- highway chain (modules.py:297-319 applied L times, modules.py:342-345) ------------------
  * All L highwaynet layers of a CBHG block in one launch (bf16, H = 128 or 256): a block keeps its
- * 128 frames in LDS across the layers, weights stream from L2 in MFMA fragment order.
- * vc_highway_pack: d_Bt = the paired [2H, H] bf16 matrix of vc_conv_gemm's VC_GEMM_HIGHWAY mode
- * (rows 64q..64q+31 = dense1 columns of units 32q.., rows 64q+32.. = dense2) -> d_packed [2H*H] bf16.
- * vc_highway_chain: d_packed / d_bias are HOST arrays of n_layers (<= 8) device pointers
- * (bias: float32 [2H] in the same paired order).  Results are bit-identical to n_layers launches of
- * vc_conv_gemm(VC_GEMM_HIGHWAY).  d_Y may equal d_X. */
-int vc_highway_pack(const void* d_Bt, int32_t H, void* d_packed, void* stream);
+ * 128 frames in LDS across the layers, weights stream from L2 in MFMA fragment order; optionally
+ * followed, on the same on-chip activations, by the GRU's input projection (modules.py:346,
+ * GRUCell x-halves of both directions: a dense layer H -> n_proj with float32 output).
+ * vc_highway_pack: d_Bt [n_cols, H] bf16, K contiguous (for the highway layers the paired [2H, H]
+ * matrix of vc_conv_gemm's VC_GEMM_HIGHWAY mode: rows 64q..64q+31 = dense1 columns of units 32q..,
+ * rows 64q+32.. = dense2) -> d_packed [n_cols*H] bf16 in fragment order.
+ * vc_highway_chain: d_packed / d_bias are HOST arrays of n_layers (0..8) device pointers (bias:
+ * float32 [2H], paired order).  d_Y [M, ldy] bf16 receives the last layer's output (NULL: not
+ * stored; may equal d_X).  d_proj_packed (NULL: no tail) / d_proj_bias [n_proj] / d_P [M, ldp]
+ * float32.  Bit-identical to n_layers launches of vc_conv_gemm(VC_GEMM_HIGHWAY) + one dense launch. */
+int vc_highway_pack(const void* d_Bt, int32_t n_cols, int32_t H, void* d_packed, void* stream);
 int vc_highway_chain(const void* d_X, int32_t M, int32_t H, int32_t ldx, int32_t n_layers,
-                     const void* const* d_packed, const float* const* d_bias, void* d_Y, int32_t ldy, void* stream);
+                     const void* const* d_packed, const float* const* d_bias, void* d_Y, int32_t ldy,
+                     const void* d_proj_packed, const float* d_proj_bias, int32_t n_proj, float* d_P, int32_t ldp,
+                     void* stream);
 
 /* ---- on-device feature cache -----------------------------------
  * dst[r, :] = src[index[r], :] for index[r] >= 0, else pad_row (zeros when d_pad_row is NULL).

@@ -114,8 +114,9 @@ _SIGS = {
     'vc_gru_train_forward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     'vc_gru_backward': (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     'vc_conv_gemm_epi_pool_supported': (C.c_int, [C.POINTER(GemmDesc)]),
-    'vc_highway_pack': (C.c_int, [_P, C.c_int32, _P, _P]),
-    'vc_highway_chain': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(_P), _P, C.c_int32, _P]),
+    'vc_highway_pack': (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+    'vc_highway_chain': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(_P), _P, C.c_int32,
+                                   _P, _P, C.c_int32, _P, C.c_int32, _P]),
     'vc_gather_rows': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     'vc_vocoder_plan_create': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
     'vc_vocoder_plan_destroy': (None, [_P]),

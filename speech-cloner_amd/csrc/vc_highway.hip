@@ -36,7 +36,56 @@ struct HwChainArgs {
     int32_t M, ldx, ldy, n_layers;
     const __bf16* W[HW_MAX_LAYERS];     // packed [2H/64][H/16][2][64][8]
     const float* bias[HW_MAX_LAYERS];   // [2H] in the paired order
+    // optional tail: a dense layer over the final activations (the GRU's input projection,
+    // modules.py:197-201 -> GRUCell's x-halves), float32 output, no activation
+    const __bf16* PW;                   // packed [NP/64][H/16][2][64][8], or NULL
+    const float* Pbias;                 // [NP]
+    float* P;                           // [M, ldp]
+    int32_t NP, ldp;
 };
+
+// One 128 x 64 accumulator tile over K = H: 4 frame tiles x (2 weight fragments) per k-step.
+// Weight fragments come from a 4-deep register ring that is refilled 4 k-steps ahead -- from this
+// tile's own stream, or from `next` (the first steps of whatever tile follows) near the end.  The
+// outer loop is kept rolled so the loads address off ONE running pointer (fully unrolled, hipcc
+// materialises a 64-bit address per load and spills).
+template <int H>
+__device__ __forceinline__ void hw_tile(const bf16x8* pw, const bf16x8* next, const char* xrow, int lh, int x15,
+                                        bf16x8 (&ring)[HW_RING][2], f32x16 (&acc)[4][2]) {
+    constexpr int KS = H / 16, RB = 2 * H;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
+    bf16x8 xf[2][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xf[0][i] = *reinterpret_cast<const bf16x8*>(xrow + i * 32 * RB + ((lh ^ x15) << 4));
+#pragma unroll 1
+    for (int s0 = 0; s0 < KS; s0 += HW_RING) {
+        const bf16x8* src = (s0 + HW_RING < KS) ? pw + (size_t)(s0 + HW_RING) * 128 : next;
+#pragma unroll
+        for (int u = 0; u < HW_RING; ++u) {
+            const int s = s0 + u, cb = u & 1;
+            if (s + 1 < KS) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    xf[cb ^ 1][i] = *reinterpret_cast<const bf16x8*>(xrow + i * 32 * RB + (((2 * (s + 1) + lh) ^ x15) << 4));
+            }
+            const bf16x8 w0 = ring[u][0], w1 = ring[u][1];
+            if (src) {
+                ring[u][0] = src[u * 128];
+                ring[u][1] = src[u * 128 + 64];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[cb][i], acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[cb][i], acc[i][1], 0, 0, 0);
+            }
+        }
+    }
+}
 
 template <int H>
 __global__ void __launch_bounds__(2 * H, H == 256 ? 1 : 2)
@@ -68,11 +117,13 @@ highway_chain_kernel(HwChainArgs a) {
     auto wptr = [&](int layer, int s) {
         return reinterpret_cast<const bf16x8*>(a.W[layer]) + ((size_t)(w * KS + s) * 2) * 64 + lane;
     };
+    if (a.n_layers > 0) {
 #pragma unroll
-    for (int s = 0; s < HW_RING; ++s) {
-        const bf16x8* p = wptr(0, s);
-        wr[s][0] = p[0];
-        wr[s][1] = p[64];
+        for (int s = 0; s < HW_RING; ++s) {
+            const bf16x8* p = wptr(0, s);
+            wr[s][0] = p[0];
+            wr[s][1] = p[64];
+        }
     }
     __syncthreads();
 
@@ -81,45 +132,8 @@ highway_chain_kernel(HwChainArgs a) {
         char* nxt = smem + ((layer & 1) ^ 1) * (HW_BM * RB);
         const bool more = layer + 1 < a.n_layers;
         f32x16 acc[4][2];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][c][r] = 0.0f;
-
-        bf16x8 xf[2][4];
-        const char* xrow = cur + li * RB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) xf[0][i] = *reinterpret_cast<const bf16x8*>(xrow + i * 32 * RB + ((lh ^ x15) << 4));
-#pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int cb = s & 1;
-            if (s + 1 < KS) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    xf[cb ^ 1][i] = *reinterpret_cast<const bf16x8*>(xrow + i * 32 * RB + (((2 * (s + 1) + lh) ^ x15) << 4));
-            }
-            const bf16x8 w0 = wr[s % HW_RING][0], w1 = wr[s % HW_RING][1];
-            // refill the ring slot just consumed: step s + RING of this layer, or of the next one
-            {
-                const int sn = s + HW_RING;
-                if (sn < KS) {
-                    const bf16x8* p = wptr(layer, sn);
-                    wr[s % HW_RING][0] = p[0];
-                    wr[s % HW_RING][1] = p[64];
-                } else if (more) {
-                    const bf16x8* p = wptr(layer + 1, sn - KS);
-                    wr[s % HW_RING][0] = p[0];
-                    wr[s % HW_RING][1] = p[64];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, xf[cb][i], acc[i][0], 0, 0, 0);
-                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, xf[cb][i], acc[i][1], 0, 0, 0);
-            }
-        }
+        const bf16x8* nextw = more ? wptr(layer + 1, 0) : (a.PW ? reinterpret_cast<const bf16x8*>(a.PW) + ((size_t)w * KS * 2) * 64 + lane : nullptr);
+        hw_tile<H>(wptr(layer, 0), nextw, cur + li * RB, lh, x15, wr, acc);
         // ---- gate (lane-local) -> next activation tile
         f32x4h bH[4], bT[4];
 #pragma unroll
@@ -144,8 +158,43 @@ highway_chain_kernel(HwChainArgs a) {
         __syncthreads();
     }
 
-    // ---- final tile -> global
     const char* fin = smem + (a.n_layers & 1) * (HW_BM * RB);
+    // ---- tail projection: P[frame, n] = sum_k X[frame, k] * PW[n, k] + Pbias[n], 64 columns per wave
+    // and pass (lane = frame; a register quad = 4 consecutive columns -> 16-byte float32 stores)
+    if (a.PW) {
+        constexpr int NW = 2 * H / 64;
+        const int ngroups = a.NP / 64;
+        const char* xrow = fin + li * RB;
+        if (a.n_layers == 0) {
+            const bf16x8* p0 = reinterpret_cast<const bf16x8*>(a.PW) + ((size_t)w * KS * 2) * 64 + lane;
+#pragma unroll
+            for (int s = 0; s < HW_RING; ++s) { wr[s][0] = p0[s * 128]; wr[s][1] = p0[s * 128 + 64]; }
+        }
+        for (int grp = w; grp < ngroups; grp += NW) {
+            const bf16x8* pw = reinterpret_cast<const bf16x8*>(a.PW) + ((size_t)grp * KS * 2) * 64 + lane;
+            const bf16x8* nextw = (grp + NW < ngroups) ? pw + (size_t)NW * KS * 128 : nullptr;
+            f32x16 acc[4][2];
+            hw_tile<H>(pw, nextw, xrow, lh, x15, wr, acc);
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = grp * 64 + c * 32 + 8 * q + 4 * lh;
+                    const f32x4h bb = *reinterpret_cast<const f32x4h*>(a.Pbias + n);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int gm = m0 + i * 32 + li;
+                        f32x4h o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = acc[i][c][4 * q + e] + bb[e];
+                        if (gm < a.M) *reinterpret_cast<f32x4h*>(a.P + (size_t)gm * a.ldp + n) = o;
+                    }
+                }
+            }
+        }
+    }
+    if (a.Y == nullptr) return;
+    // ---- final tile -> global
     for (int idx = tid; idx < HW_BM * NS; idx += NT) {
         const int row = idx / NS, slot = idx - row * NS;
         const int gm = m0 + row;
@@ -168,10 +217,10 @@ template <int H> int launch_chain(const HwChainArgs& a, hipStream_t st) {
     return VC_OK;
 }
 
-// packed[w][s][c][lane][j] = Bt[w*64 + c*32 + (lane & 31)][s*16 + (lane >> 5)*8 + j]
+// packed[w][s][c][lane][j] = Bt[w*64 + c*32 + (lane & 31)][s*16 + (lane >> 5)*8 + j]   (Bt: [ncols][H])
 __global__ void __launch_bounds__(256)
-highway_pack_kernel(const __bf16* Bt, int H, __bf16* packed) {
-    const int KS = H / 16, total = (2 * H / 64) * KS * 2 * 64 * 8;
+highway_pack_kernel(const __bf16* Bt, int ncols, int H, __bf16* packed) {
+    const int KS = H / 16, total = (ncols / 64) * KS * 2 * 64 * 8;
     for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
         int r = idx;
         const int j = r & 7; r >>= 3;
@@ -187,24 +236,32 @@ highway_pack_kernel(const __bf16* Bt, int H, __bf16* packed) {
 
 extern "C" {
 
-int vc_highway_pack(const void* d_Bt, int32_t H, void* d_packed, void* stream) {
-    VC_REQUIRE(d_Bt && d_packed && (H == 128 || H == 256), "vc_highway_pack: H must be 128 or 256");
+int vc_highway_pack(const void* d_Bt, int32_t n_cols, int32_t H, void* d_packed, void* stream) {
+    VC_REQUIRE(d_Bt && d_packed && (H == 128 || H == 256) && n_cols > 0 && n_cols % 64 == 0,
+               "vc_highway_pack: H must be 128 or 256 and n_cols a multiple of 64");
     hipLaunchKernelGGL(highway_pack_kernel, dim3(128), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       static_cast<const __bf16*>(d_Bt), H, static_cast<__bf16*>(d_packed));
+                       static_cast<const __bf16*>(d_Bt), n_cols, H, static_cast<__bf16*>(d_packed));
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }
 
 int vc_highway_chain(const void* d_X, int32_t M, int32_t H, int32_t ldx, int32_t n_layers, const void* const* d_packed,
-                     const float* const* d_bias, void* d_Y, int32_t ldy, void* stream) {
-    VC_REQUIRE(d_X && d_Y && d_packed && d_bias, "vc_highway_chain: NULL argument");
+                     const float* const* d_bias, void* d_Y, int32_t ldy, const void* d_proj_packed,
+                     const float* d_proj_bias, int32_t n_proj, float* d_P, int32_t ldp, void* stream) {
+    VC_REQUIRE(d_X && d_packed && d_bias && (d_Y || d_proj_packed), "vc_highway_chain: NULL argument");
+    if (d_proj_packed)
+        VC_REQUIRE(d_proj_bias && d_P && n_proj > 0 && n_proj % 64 == 0 && ldp >= n_proj && ldp % 4 == 0 &&
+                       ((reinterpret_cast<uintptr_t>(d_proj_packed) | reinterpret_cast<uintptr_t>(d_proj_bias) |
+                         reinterpret_cast<uintptr_t>(d_P)) & 15) == 0,
+                   "vc_highway_chain: projection tail needs bias, output, n_proj %% 64 == 0, 16-byte aligned operands");
     VC_REQUIRE(H == 128 || H == 256, "vc_highway_chain: H must be 128 or 256 (got %d)", H);
-    VC_REQUIRE(M > 0 && n_layers >= 1 && n_layers <= HW_MAX_LAYERS, "vc_highway_chain: bad M / n_layers");
-    VC_REQUIRE(ldx >= H && ldy >= H && ldx % 8 == 0 && ldy % 8 == 0, "vc_highway_chain: ldx / ldy must be multiples of 8 and >= H");
+    VC_REQUIRE(M > 0 && n_layers >= 0 && n_layers <= HW_MAX_LAYERS, "vc_highway_chain: bad M / n_layers");
+    VC_REQUIRE(ldx >= H && ldx % 8 == 0 && (!d_Y || (ldy >= H && ldy % 8 == 0)), "vc_highway_chain: ldx / ldy must be multiples of 8 and >= H");
     VC_REQUIRE(((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_Y)) & 15) == 0, "vc_highway_chain: X / Y must be 16-byte aligned");
     HwChainArgs a;
     a.X = static_cast<const __bf16*>(d_X); a.Y = static_cast<__bf16*>(d_Y);
     a.M = M; a.ldx = ldx; a.ldy = ldy; a.n_layers = n_layers;
+    a.PW = static_cast<const __bf16*>(d_proj_packed); a.Pbias = d_proj_bias; a.P = d_P; a.NP = n_proj; a.ldp = ldp;
     for (int l = 0; l < n_layers; ++l) {
         VC_REQUIRE(d_packed[l] && d_bias[l] && (reinterpret_cast<uintptr_t>(d_packed[l]) & 15) == 0 &&
                        (reinterpret_cast<uintptr_t>(d_bias[l]) & 15) == 0, "vc_highway_chain: layer %d operands NULL or misaligned", l);

@@ -419,6 +419,14 @@ def gru(inputs, num_units=None, bidirection=False, scope="gru", use_Cudnn=False,
     xproj = torch.empty((N_ * T_, 6 * H), dtype=torch.float32, device=x.device)
     gemm_launch(x, N_ * T_, T_, Cin, Cin, 6 * H, [(btx, Cin, 1, 0, 0)], xproj, 6 * H, store.vc_dtype,
                 epi_shift=bx, out_f32=True)
+    return _gru_recurrence(xproj, N_, T_, H, wh_fw, wh_bw)
+
+
+def _gru_recurrence(xproj, N_, T_, H, wh_fw, wh_bw):
+    """The recurrent half of gru(): xproj [N*T, 6H] float32 = input projections of both directions."""
+    torch = _torch()
+    store = _store()
+    x = xproj
     out = torch.empty((N_, T_, 2 * H), dtype=store.dtype, device=x.device)
     nws = _vc.lib().vc_gru_workspace_bytes(H, store.vc_dtype)
     ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=x.device)
@@ -469,10 +477,12 @@ def highwaynet(inputs, num_units=None, scope="highwaynet", reuse=None):
     return out
 
 
-def highway_chain(inputs, num_units, n_layers, scope_fmt='highwaynet_{}'):
+def highway_chain(inputs, num_units, n_layers, scope_fmt='highwaynet_{}', gru_scope=None):
     """n_layers consecutive highwaynet blocks (modules.py:342-345).  bf16 with 128 or 256 units and at
     least 128 frames runs as ONE launch that keeps the activations on chip (vc_highway_chain);
-    anything else is the per-layer launch.  Same results either way (bit-identical)."""
+    anything else is the per-layer launch.  Same results either way (bit-identical).
+    gru_scope: also apply the bidirectional GRU of that scope (modules.py:346) -- in the fused form
+    its input projection is the tail of the same launch and the highway output never reaches HBM."""
     torch = _torch()
     store = _store()
     x = _as3(inputs)
@@ -483,7 +493,7 @@ def highway_chain(inputs, num_units, n_layers, scope_fmt='highwaynet_{}'):
         out = x
         for i in range(n_layers):
             out = highwaynet(out, num_units=num_units, scope=scope_fmt.format(i))
-        return out
+        return out if gru_scope is None else gru(out, num_units=num_units, bidirection=True, scope=gru_scope)
     packed, biases = [], []
     for i in range(n_layers):
         sc = _scope(scope_fmt.format(i))
@@ -491,17 +501,32 @@ def highway_chain(inputs, num_units, n_layers, scope_fmt='highwaynet_{}'):
 
         def build(bt=bt):
             pk = torch.empty(bt.numel(), dtype=store.dtype, device=store.device)
-            _vc.check(_vc.lib().vc_highway_pack(bt.data_ptr(), Cx, pk.data_ptr(), _vc.current_stream()))
+            _vc.check(_vc.lib().vc_highway_pack(bt.data_ptr(), bt.shape[0], Cx, pk.data_ptr(), _vc.current_stream()))
             return pk
         packed.append(store.cached(('highway_pk', sc), build))
         biases.append(bias)
     x = x.contiguous()
-    out = torch.empty_like(x)
     PA = (C.c_void_p * n_layers)(*[p.data_ptr() for p in packed])
     BA = (C.c_void_p * n_layers)(*[b.data_ptr() for b in biases])
-    _vc.check(_vc.lib().vc_highway_chain(x.data_ptr(), N_ * T_, Cx, Cx, n_layers, PA, BA, out.data_ptr(), Cx,
+    if gru_scope is None:
+        out = torch.empty_like(x)
+        _vc.check(_vc.lib().vc_highway_chain(x.data_ptr(), N_ * T_, Cx, Cx, n_layers, PA, BA, out.data_ptr(), Cx,
+                                             None, None, 0, None, 0, _vc.current_stream()))
+        return out
+    H = num_units
+    gsc = _scope(gru_scope)
+    btx, bx, wh_fw, wh_bw = _prep_gru(store, gsc, Cx, H)
+
+    def build_px():
+        pk = torch.empty(btx.numel(), dtype=store.dtype, device=store.device)
+        _vc.check(_vc.lib().vc_highway_pack(btx.data_ptr(), btx.shape[0], Cx, pk.data_ptr(), _vc.current_stream()))
+        return pk
+    px = store.cached(('gru_pk', gsc), build_px)
+    xproj = torch.empty((N_ * T_, 6 * H), dtype=torch.float32, device=x.device)
+    _vc.check(_vc.lib().vc_highway_chain(x.data_ptr(), N_ * T_, Cx, Cx, n_layers, PA, BA, None, 0,
+                                         px.data_ptr(), bx.data_ptr(), 6 * H, xproj.data_ptr(), 6 * H,
                                          _vc.current_stream()))
-    return out
+    return _gru_recurrence(xproj, N_, T_, H, wh_fw, wh_bw)
 
 
 def CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dropout_rate=0.5, is_training=True,
@@ -517,8 +542,8 @@ def CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dro
                      activation_fn='relu', pool_input=0 if pooled else 2)                  # (N, T, E/2)
         enc = conv1d(enc, filters=embed_size // 2, size=3, scope="conv1d_2", bn_scope="conv1d_2",
                      residual=inputs)                                                      # + residual
-        enc = highway_chain(enc, embed_size // 2, num_highwaynet_blocks)
-        output = gru(enc, num_units=embed_size // 2, bidirection=True, use_Cudnn=use_Cudnn)  # (N, T, E)
+        # highway blocks + bidirectional GRU (modules.py:342-346)
+        output = highway_chain(enc, embed_size // 2, num_highwaynet_blocks, gru_scope='gru')    # (N, T, E)
     return output
 
 

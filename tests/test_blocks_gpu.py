@@ -269,12 +269,15 @@ def test_highway_chain_single_launch(N, T, H, L, monkeypatch):
             st.assign('h/highwaynet_%d/dense1/bias' % i, rng.uniform(-0.2, 0.2, H).astype(np.float32))
             st.assign('h/highwaynet_%d/dense2/bias' % i, rng.uniform(-1.2, 0.2, H).astype(np.float32))
         y_ref = modules.highway_chain(xd, H, L)
+        g_ref = modules.highway_chain(xd, H, L, gru_scope='gru')          # per-layer launches + dense + recurrence
         monkeypatch.setenv('VC_HIGHWAY_CHAIN', '1')
         poison_gpu_state()
         y = modules.highway_chain(xd, H, L)
+        g = modules.highway_chain(xd, H, L, gru_scope='gru')              # the GRU's input projection rides on the chain
     torch.cuda.synchronize()
     assert not torch.isnan(y.float()).any()
     assert torch.equal(y, y_ref)
+    assert g.shape == (N, T, 2 * H) and torch.equal(g, g_ref)
     cast = lambda t: t.float().bfloat16().double()
     w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
     ref = cast(x)
