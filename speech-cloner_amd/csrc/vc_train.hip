@@ -439,12 +439,43 @@ gru_bwd_kernel(GruBwdArgs a) {
 // The one-sequence kernels above re-read the whole recurrent matrix (3H^2 floats = 786 KB at H = 256)
 // from L2 every step.  Here a workgroup advances S windows of one direction, so every weight
 // load feeds S FMAs; h lives in LDS as [S][H] and is read back as float4 broadcasts.
+// acc[s] += sum_k vec[s][k] * w[k * stride]  for k in [0, n): the weight column is read in batches
+// of 16 independent loads (a 4-load batch per iteration left each wave waiting on L2 64-128 times
+// per phase and step: the recurrences were latency-bound).  n must be a multiple of 4.
+template <int S>
+__device__ __forceinline__ void ms_matvec(const float* __restrict__ w, size_t stride, const float* vec, int vstride, int n,
+                                          float (&acc)[S]) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    int k = 0;
+    for (; k + 16 <= n; k += 16) {
+        float wv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) wv[u] = w[(size_t)(k + u) * stride];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const f4 v = *reinterpret_cast<const f4*>(vec + s * vstride + k + 4 * q);
+                acc[s] = fmaf(v[0], wv[4 * q], acc[s]); acc[s] = fmaf(v[1], wv[4 * q + 1], acc[s]);
+                acc[s] = fmaf(v[2], wv[4 * q + 2], acc[s]); acc[s] = fmaf(v[3], wv[4 * q + 3], acc[s]);
+            }
+    }
+    for (; k < n; k += 4) {
+        const float w0 = w[(size_t)k * stride], w1 = w[(size_t)(k + 1) * stride], w2 = w[(size_t)(k + 2) * stride], w3 = w[(size_t)(k + 3) * stride];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const f4 v = *reinterpret_cast<const f4*>(vec + s * vstride + k);
+            acc[s] = fmaf(v[0], w0, acc[s]); acc[s] = fmaf(v[1], w1, acc[s]);
+            acc[s] = fmaf(v[2], w2, acc[s]); acc[s] = fmaf(v[3], w3, acc[s]);
+        }
+    }
+}
+
 constexpr int GS = 4;
 
 __global__ void __launch_bounds__(512)
 gru_train_fwd_ms_kernel(GruTrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef float f4 __attribute__((ext_vector_type(4)));
     const int H = a.H, H3 = 3 * H, NT = blockDim.x, tid = threadIdx.x;
     float* h = reinterpret_cast<float*>(smem);      // [GS][H]
     float* rhs = h + GS * H;                        // [GS][H]
@@ -467,16 +498,7 @@ gru_train_fwd_ms_kernel(GruTrainArgs a) {
             float acc[GS];
 #pragma unroll
             for (int s = 0; s < GS; ++s) acc[s] = a.xproj[((size_t)sq[s] * a.T + t) * xrow + (size_t)dir * H3 + col];
-            const float* w = W + col;
-            for (int k = 0; k < H; k += 4) {
-                const float w0 = w[(size_t)k * H3], w1 = w[(size_t)(k + 1) * H3], w2 = w[(size_t)(k + 2) * H3], w3 = w[(size_t)(k + 3) * H3];
-#pragma unroll
-                for (int s = 0; s < GS; ++s) {
-                    const f4 hv = *reinterpret_cast<const f4*>(h + s * H + k);
-                    acc[s] = fmaf(hv[0], w0, acc[s]); acc[s] = fmaf(hv[1], w1, acc[s]);
-                    acc[s] = fmaf(hv[2], w2, acc[s]); acc[s] = fmaf(hv[3], w3, acc[s]);
-                }
-            }
+            ms_matvec<GS>(W + col, (size_t)H3, h, H, H, acc);
 #pragma unroll
             for (int s = 0; s < GS; ++s) {
                 const float g = sigmoidf_(acc[s]);
@@ -497,16 +519,7 @@ gru_train_fwd_ms_kernel(GruTrainArgs a) {
             float acc[GS];
 #pragma unroll
             for (int s = 0; s < GS; ++s) acc[s] = a.xproj[((size_t)sq[s] * a.T + t) * xrow + (size_t)dir * H3 + 2 * H + col];
-            const float* w = W + 2 * H + col;
-            for (int k = 0; k < H; k += 4) {
-                const float w0 = w[(size_t)k * H3], w1 = w[(size_t)(k + 1) * H3], w2 = w[(size_t)(k + 2) * H3], w3 = w[(size_t)(k + 3) * H3];
-#pragma unroll
-                for (int s = 0; s < GS; ++s) {
-                    const f4 rv = *reinterpret_cast<const f4*>(rhs + s * H + k);
-                    acc[s] = fmaf(rv[0], w0, acc[s]); acc[s] = fmaf(rv[1], w1, acc[s]);
-                    acc[s] = fmaf(rv[2], w2, acc[s]); acc[s] = fmaf(rv[3], w3, acc[s]);
-                }
-            }
+            ms_matvec<GS>(W + 2 * H + col, (size_t)H3, rhs, H, H, acc);
 #pragma unroll
             for (int s = 0; s < GS; ++s) {
                 const float c = tanhf(acc[s]);
@@ -536,7 +549,6 @@ struct GruBwdMsArgs {
 __global__ void __launch_bounds__(512)
 gru_bwd_ms_kernel(GruBwdMsArgs aa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    typedef float f4 __attribute__((ext_vector_type(4)));
     const GruBwdArgs& a = aa.b;
     const int H = a.H, H3 = 3 * H, NT = blockDim.x, tid = threadIdx.x;
     float* dh = reinterpret_cast<float*>(smem);     // [GS][H]
@@ -572,16 +584,7 @@ gru_bwd_ms_kernel(GruBwdMsArgs aa) {
             float acc[GS];
 #pragma unroll
             for (int s = 0; s < GS; ++s) acc[s] = 0.0f;
-            const float* w = WT + (size_t)2 * H * H + k;
-            for (int j = 0; j < H; j += 4) {
-                const float w0 = w[(size_t)j * H], w1 = w[(size_t)(j + 1) * H], w2 = w[(size_t)(j + 2) * H], w3 = w[(size_t)(j + 3) * H];
-#pragma unroll
-                for (int s = 0; s < GS; ++s) {
-                    const f4 v = *reinterpret_cast<const f4*>(dcp + s * H + j);
-                    acc[s] = fmaf(w0, v[0], acc[s]); acc[s] = fmaf(w1, v[1], acc[s]);
-                    acc[s] = fmaf(w2, v[2], acc[s]); acc[s] = fmaf(w3, v[3], acc[s]);
-                }
-            }
+            ms_matvec<GS>(WT + (size_t)2 * H * H + k, (size_t)H, dcp, H, H, acc);
 #pragma unroll
             for (int s = 0; s < GS; ++s) drh[s * H + k] = acc[s];
         }
@@ -600,16 +603,7 @@ gru_bwd_ms_kernel(GruBwdMsArgs aa) {
             float acc[GS];
 #pragma unroll
             for (int s = 0; s < GS; ++s) acc[s] = 0.0f;
-            const float* w = WT + k;
-            for (int j = 0; j < 2 * H; j += 4) {
-                const float w0 = w[(size_t)j * H], w1 = w[(size_t)(j + 1) * H], w2 = w[(size_t)(j + 2) * H], w3 = w[(size_t)(j + 3) * H];
-#pragma unroll
-                for (int s = 0; s < GS; ++s) {
-                    const f4 v = *reinterpret_cast<const f4*>(dgp + s * 2 * H + j);
-                    acc[s] = fmaf(w0, v[0], acc[s]); acc[s] = fmaf(w1, v[1], acc[s]);
-                    acc[s] = fmaf(w2, v[2], acc[s]); acc[s] = fmaf(w3, v[3], acc[s]);
-                }
-            }
+            ms_matvec<GS>(WT + k, (size_t)H, dgp, 2 * H, 2 * H, acc);
 #pragma unroll
             for (int s = 0; s < GS; ++s) dh[s * H + k] += acc[s];
         }
