@@ -555,6 +555,11 @@ gru_bwd_ms_kernel(GruBwdMsArgs aa) {
     float* dcp = dh + GS * H;                       // [GS][H]
     float* dgp = dcp + GS * H;                      // [GS][2H]
     float* drh = dgp + GS * 2 * H;                  // [GS][H]
+    float* part = drh + GS * H;                     // [P][GS][H] partial sums of the split reductions
+    // A W^T matvec has only H outputs for NT threads: the reduction index is split over P = NT / H
+    // thread groups (each sums a contiguous slice), partials meet in LDS.
+    const int P = (NT >= H && NT % H == 0) ? NT / H : 1;
+    const int pk = P > 1 ? tid % H : tid, pp = P > 1 ? tid / H : 0;
     const int seq0 = blockIdx.x * GS, dir = blockIdx.y;
     const float* WT = aa.WhT[dir];                  // WT[col][k] = W[k][col]
     const size_t MT = (size_t)a.n_seq * a.T;
@@ -580,13 +585,29 @@ gru_bwd_ms_kernel(GruBwdMsArgs aa) {
         }
         __syncthreads();
         // d(rh)[k] = sum_j W[k][2H + j] dc_pre[j] = sum_j WT[2H + j][k] dc_pre[j]
-        for (int k = tid; k < H; k += NT) {
+        if (P > 1) {
             float acc[GS];
 #pragma unroll
             for (int s = 0; s < GS; ++s) acc[s] = 0.0f;
-            ms_matvec<GS>(WT + (size_t)2 * H * H + k, (size_t)H, dcp, H, H, acc);
+            const int n = H / P, j0 = pp * n;
+            ms_matvec<GS>(WT + (size_t)(2 * H + j0) * H + pk, (size_t)H, dcp + j0, H, n, acc);
 #pragma unroll
-            for (int s = 0; s < GS; ++s) drh[s * H + k] = acc[s];
+            for (int s = 0; s < GS; ++s) part[(pp * GS + s) * H + pk] = acc[s];
+            __syncthreads();
+            for (int i = tid; i < GS * H; i += NT) {
+                float v = part[i];
+                for (int q = 1; q < P; ++q) v += part[q * GS * H + i];
+                drh[i] = v;
+            }
+        } else {
+            for (int k = tid; k < H; k += NT) {
+                float acc[GS];
+#pragma unroll
+                for (int s = 0; s < GS; ++s) acc[s] = 0.0f;
+                ms_matvec<GS>(WT + (size_t)2 * H * H + k, (size_t)H, dcp, H, H, acc);
+#pragma unroll
+                for (int s = 0; s < GS; ++s) drh[s * H + k] = acc[s];
+            }
         }
         __syncthreads();
         for (int i = tid; i < GS * H; i += NT) {
@@ -599,13 +620,29 @@ gru_bwd_ms_kernel(GruBwdMsArgs aa) {
         }
         __syncthreads();
         // dh_prev[k] += sum_{j < 2H} W[k][j] dg_pre[j] = sum_j WT[j][k] dg_pre[j]
-        for (int k = tid; k < H; k += NT) {
+        if (P > 1) {
             float acc[GS];
 #pragma unroll
             for (int s = 0; s < GS; ++s) acc[s] = 0.0f;
-            ms_matvec<GS>(WT + k, (size_t)H, dgp, 2 * H, 2 * H, acc);
+            const int n = 2 * H / P, j0 = pp * n;
+            ms_matvec<GS>(WT + (size_t)j0 * H + pk, (size_t)H, dgp + j0, 2 * H, n, acc);
 #pragma unroll
-            for (int s = 0; s < GS; ++s) dh[s * H + k] += acc[s];
+            for (int s = 0; s < GS; ++s) part[(pp * GS + s) * H + pk] = acc[s];
+            __syncthreads();
+            for (int i = tid; i < GS * H; i += NT) {
+                float v = part[i];
+                for (int q = 1; q < P; ++q) v += part[q * GS * H + i];
+                dh[i] += v;
+            }
+        } else {
+            for (int k = tid; k < H; k += NT) {
+                float acc[GS];
+#pragma unroll
+                for (int s = 0; s < GS; ++s) acc[s] = 0.0f;
+                ms_matvec<GS>(WT + k, (size_t)H, dgp, 2 * H, 2 * H, acc);
+#pragma unroll
+                for (int s = 0; s < GS; ++s) dh[s * H + k] += acc[s];
+            }
         }
         for (int i = tid; i < GS * 3 * H; i += NT) {
             const int s = i / H3, j = i - s * H3;
@@ -844,7 +881,7 @@ int vc_gru_backward(const float* d_dout, const float* d_out, const float* d_gate
     if (d_WhT_fw && d_WhT_bw && H % 4 == 0) {             // multi-sequence kernel with transposed weights
         GruBwdMsArgs aa;
         aa.b = a; aa.WhT[0] = d_WhT_fw; aa.WhT[1] = d_WhT_bw;
-        hipLaunchKernelGGL(gru_bwd_ms_kernel, dim3((n_seq + GS - 1) / GS, 2), dim3(nt), 5 * (size_t)GS * H * 4,
+        hipLaunchKernelGGL(gru_bwd_ms_kernel, dim3((n_seq + GS - 1) / GS, 2), dim3(nt), (5 + (size_t)(nt >= H ? nt / H : 1)) * GS * H * 4,
                            static_cast<hipStream_t>(stream), aa);
     } else
         hipLaunchKernelGGL(gru_bwd_kernel, dim3(n_seq, 2), dim3(nt), 5 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
