@@ -480,6 +480,9 @@ gru_train_fwd_ms_kernel(GruTrainArgs a) {
     float* h = reinterpret_cast<float*>(smem);      // [GS][H]
     float* rhs = h + GS * H;                        // [GS][H]
     float* us = rhs + GS * H;                       // [GS][H]
+    float* part = us + GS * H;                      // [P][GS][H] partial sums of the candidate matvec
+    const int P = (NT >= H && NT % H == 0) ? NT / H : 1;   // the candidate has H columns for NT threads
+    const int pk = P > 1 ? tid % H : tid, pp = P > 1 ? tid / H : 0;
     const int seq0 = blockIdx.x * GS, dir = blockIdx.y;
     const float* W = a.Wh[dir];
     const size_t MT = (size_t)a.n_seq * a.T;
@@ -515,11 +518,27 @@ gru_train_fwd_ms_kernel(GruTrainArgs a) {
         }
         __syncthreads();
         float hn[GS];
+        if (P > 1) {                                     // reduction index split over P thread groups
+            float pacc[GS];
+#pragma unroll
+            for (int s = 0; s < GS; ++s) pacc[s] = 0.0f;
+            const int n = H / P, k0 = pp * n;
+            ms_matvec<GS>(W + (size_t)k0 * H3 + 2 * H + pk, (size_t)H3, rhs + k0, H, n, pacc);
+#pragma unroll
+            for (int s = 0; s < GS; ++s) part[(pp * GS + s) * H + pk] = pacc[s];
+            __syncthreads();
+        }
         for (int col = tid; col < H; col += NT) {
             float acc[GS];
 #pragma unroll
             for (int s = 0; s < GS; ++s) acc[s] = a.xproj[((size_t)sq[s] * a.T + t) * xrow + (size_t)dir * H3 + 2 * H + col];
-            ms_matvec<GS>(W + 2 * H + col, (size_t)H3, rhs, H, H, acc);
+            if (P > 1) {
+#pragma unroll
+                for (int s = 0; s < GS; ++s)
+                    for (int q = 0; q < P; ++q) acc[s] += part[(q * GS + s) * H + col];
+            } else {
+                ms_matvec<GS>(W + 2 * H + col, (size_t)H3, rhs, H, H, acc);
+            }
 #pragma unroll
             for (int s = 0; s < GS; ++s) {
                 const float c = tanhf(acc[s]);
@@ -860,7 +879,7 @@ int vc_gru_train_forward(const float* d_xproj, const float* d_Wh_fw, const float
     a.n_seq = n_seq; a.T = T; a.H = H;
     const int nt = H >= 128 ? 512 : 256;
     if (H % 4 == 0 && H <= nt) {                          // multi-sequence kernel (GS windows per workgroup)
-        const size_t lds = 3 * (size_t)GS * H * 4;
+        const size_t lds = (3 + (size_t)(nt / H)) * GS * H * 4;
         hipLaunchKernelGGL(gru_train_fwd_ms_kernel, dim3((n_seq + GS - 1) / GS, 2), dim3(nt), lds, static_cast<hipStream_t>(stream), a);
     } else {
         hipLaunchKernelGGL(gru_train_fwd_kernel, dim3(n_seq, 2), dim3(nt), 3 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
