@@ -471,8 +471,10 @@ __device__ __forceinline__ void ms_matvec(const float* __restrict__ w, size_t st
     }
 }
 
-constexpr int GS = 4;
 
+static inline int gru_group_size(int n_seq) { return 2 * n_seq <= 256 ? 1 : (n_seq <= 256 ? 2 : 4); }
+
+template <int GS>
 __global__ void __launch_bounds__(512)
 gru_train_fwd_ms_kernel(GruTrainArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -481,8 +483,11 @@ gru_train_fwd_ms_kernel(GruTrainArgs a) {
     float* rhs = h + GS * H;                        // [GS][H]
     float* us = rhs + GS * H;                       // [GS][H]
     float* part = us + GS * H;                      // [P][GS][H] partial sums of the candidate matvec
-    const int P = (NT >= H && NT % H == 0) ? NT / H : 1;   // the candidate has H columns for NT threads
-    const int pk = P > 1 ? tid % H : tid, pp = P > 1 ? tid / H : 0;
+    // the candidate has H columns for NT threads: split its reduction over P thread groups
+    // (slices stay multiples of 4: the matvec reads float4 pieces of the state vector)
+    int P = (NT >= H && NT % H == 0) ? NT / H : 1;
+    while (P > 1 && (H / P) % 4 != 0) P >>= 1;
+    const int pk = tid % H, pp = tid / H;
     const int seq0 = blockIdx.x * GS, dir = blockIdx.y;
     const float* W = a.Wh[dir];
     const size_t MT = (size_t)a.n_seq * a.T;
@@ -523,9 +528,11 @@ gru_train_fwd_ms_kernel(GruTrainArgs a) {
 #pragma unroll
             for (int s = 0; s < GS; ++s) pacc[s] = 0.0f;
             const int n = H / P, k0 = pp * n;
-            ms_matvec<GS>(W + (size_t)k0 * H3 + 2 * H + pk, (size_t)H3, rhs + k0, H, n, pacc);
+            if (pp < P) {
+                ms_matvec<GS>(W + (size_t)k0 * H3 + 2 * H + pk, (size_t)H3, rhs + k0, H, n, pacc);
 #pragma unroll
-            for (int s = 0; s < GS; ++s) part[(pp * GS + s) * H + pk] = pacc[s];
+                for (int s = 0; s < GS; ++s) part[(pp * GS + s) * H + pk] = pacc[s];
+            }
             __syncthreads();
         }
         for (int col = tid; col < H; col += NT) {
@@ -565,6 +572,7 @@ struct GruBwdMsArgs {
     const float* WhT[2];     // [3H, H] transposed recurrent weights (coalesced matvecs with W^T)
 };
 
+template <int GS>
 __global__ void __launch_bounds__(512)
 gru_bwd_ms_kernel(GruBwdMsArgs aa) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -577,8 +585,9 @@ gru_bwd_ms_kernel(GruBwdMsArgs aa) {
     float* part = drh + GS * H;                     // [P][GS][H] partial sums of the split reductions
     // A W^T matvec has only H outputs for NT threads: the reduction index is split over P = NT / H
     // thread groups (each sums a contiguous slice), partials meet in LDS.
-    const int P = (NT >= H && NT % H == 0) ? NT / H : 1;
-    const int pk = P > 1 ? tid % H : tid, pp = P > 1 ? tid / H : 0;
+    int P = (NT >= H && NT % H == 0) ? NT / H : 1;
+    while (P > 1 && (H / P) % 4 != 0) P >>= 1;
+    const int pk = tid % H, pp = tid / H;
     const int seq0 = blockIdx.x * GS, dir = blockIdx.y;
     const float* WT = aa.WhT[dir];                  // WT[col][k] = W[k][col]
     const size_t MT = (size_t)a.n_seq * a.T;
@@ -609,9 +618,11 @@ gru_bwd_ms_kernel(GruBwdMsArgs aa) {
 #pragma unroll
             for (int s = 0; s < GS; ++s) acc[s] = 0.0f;
             const int n = H / P, j0 = pp * n;
-            ms_matvec<GS>(WT + (size_t)(2 * H + j0) * H + pk, (size_t)H, dcp + j0, H, n, acc);
+            if (pp < P) {
+                ms_matvec<GS>(WT + (size_t)(2 * H + j0) * H + pk, (size_t)H, dcp + j0, H, n, acc);
 #pragma unroll
-            for (int s = 0; s < GS; ++s) part[(pp * GS + s) * H + pk] = acc[s];
+                for (int s = 0; s < GS; ++s) part[(pp * GS + s) * H + pk] = acc[s];
+            }
             __syncthreads();
             for (int i = tid; i < GS * H; i += NT) {
                 float v = part[i];
@@ -644,9 +655,11 @@ gru_bwd_ms_kernel(GruBwdMsArgs aa) {
 #pragma unroll
             for (int s = 0; s < GS; ++s) acc[s] = 0.0f;
             const int n = 2 * H / P, j0 = pp * n;
-            ms_matvec<GS>(WT + (size_t)j0 * H + pk, (size_t)H, dgp + j0, 2 * H, n, acc);
+            if (pp < P) {
+                ms_matvec<GS>(WT + (size_t)j0 * H + pk, (size_t)H, dgp + j0, 2 * H, n, acc);
 #pragma unroll
-            for (int s = 0; s < GS; ++s) part[(pp * GS + s) * H + pk] = acc[s];
+                for (int s = 0; s < GS; ++s) part[(pp * GS + s) * H + pk] = acc[s];
+            }
             __syncthreads();
             for (int i = tid; i < GS * H; i += NT) {
                 float v = part[i];
@@ -878,9 +891,17 @@ int vc_gru_train_forward(const float* d_xproj, const float* d_Wh_fw, const float
     a.xproj = d_xproj; a.Wh[0] = d_Wh_fw; a.Wh[1] = d_Wh_bw; a.out = d_out; a.gates = d_gates; a.rh = d_rh;
     a.n_seq = n_seq; a.T = T; a.H = H;
     const int nt = H >= 128 ? 512 : 256;
-    if (H % 4 == 0 && H <= nt) {                          // multi-sequence kernel (GS windows per workgroup)
-        const size_t lds = (3 + (size_t)(nt / H)) * GS * H * 4;
-        hipLaunchKernelGGL(gru_train_fwd_ms_kernel, dim3((n_seq + GS - 1) / GS, 2), dim3(nt), lds, static_cast<hipStream_t>(stream), a);
+    if (H % 4 == 0 && H <= nt) {
+        // GS windows per workgroup.  The step is latency-bound, so spreading the windows over more
+        // CUs beats amortising the weight stream: one window per workgroup while 2 * n_seq workgroups
+        // fit the chip once (62.4 -> 53.7 ms/step at 32 windows), more only beyond that.
+        const int gs = gru_group_size(n_seq);
+        const size_t lds = (3 + (size_t)(nt / H)) * gs * H * 4;
+        const dim3 grid((n_seq + gs - 1) / gs, 2);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (gs == 1) hipLaunchKernelGGL(gru_train_fwd_ms_kernel<1>, grid, dim3(nt), lds, st, a);
+        else if (gs == 2) hipLaunchKernelGGL(gru_train_fwd_ms_kernel<2>, grid, dim3(nt), lds, st, a);
+        else hipLaunchKernelGGL(gru_train_fwd_ms_kernel<4>, grid, dim3(nt), lds, st, a);
     } else {
         hipLaunchKernelGGL(gru_train_fwd_kernel, dim3(n_seq, 2), dim3(nt), 3 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
     }
@@ -900,8 +921,13 @@ int vc_gru_backward(const float* d_dout, const float* d_out, const float* d_gate
     if (d_WhT_fw && d_WhT_bw && H % 4 == 0) {             // multi-sequence kernel with transposed weights
         GruBwdMsArgs aa;
         aa.b = a; aa.WhT[0] = d_WhT_fw; aa.WhT[1] = d_WhT_bw;
-        hipLaunchKernelGGL(gru_bwd_ms_kernel, dim3((n_seq + GS - 1) / GS, 2), dim3(nt), (5 + (size_t)(nt >= H ? nt / H : 1)) * GS * H * 4,
-                           static_cast<hipStream_t>(stream), aa);
+        const int gs = gru_group_size(n_seq);
+        const size_t lds = (5 + (size_t)(nt >= H ? nt / H : 1)) * gs * H * 4;
+        const dim3 grid((n_seq + gs - 1) / gs, 2);
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        if (gs == 1) hipLaunchKernelGGL(gru_bwd_ms_kernel<1>, grid, dim3(nt), lds, st, aa);
+        else if (gs == 2) hipLaunchKernelGGL(gru_bwd_ms_kernel<2>, grid, dim3(nt), lds, st, aa);
+        else hipLaunchKernelGGL(gru_bwd_ms_kernel<4>, grid, dim3(nt), lds, st, aa);
     } else
         hipLaunchKernelGGL(gru_bwd_kernel, dim3(n_seq, 2), dim3(nt), 5 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
     VC_HIP_CHECK(hipGetLastError());
