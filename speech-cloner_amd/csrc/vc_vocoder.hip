@@ -94,8 +94,10 @@ gl_iter400_kernel(GlArgs a) {
     float* tw = win + 400;                             // [2][208]
     float* Are = tw + 416;                             // [NROW*17]
     float* Aim = Are + NROW * VA_STRIDE;
-    float* amps = Aim + NROW * VA_STRIDE;              // [VG][201]
-    float* xs = amps + VG * 201;                       // [span]  (INIT: phase tile [VG][201])
+    // INIT keeps the magnitude tile and the phase tile in LDS; the iteration kernel holds each
+    // thread's 16 target magnitudes in registers instead (38 KB of LDS: four blocks per CU)
+    float* amps = Aim + NROW * VA_STRIDE;              // INIT: [VG][201]
+    float* xs = INIT ? amps + VG * 201 : amps;         // [span]  (INIT: phase tile [VG][201])
 
     const int b = blockIdx.y, tid = threadIdx.x;
     const int F = utt_frames(a, b);
@@ -104,12 +106,22 @@ gl_iter400_kernel(GlArgs a) {
     const int nvalid = min(VG, F - f0);
 
     copy_lds(win, a.window, 816);
-    {
+    float amr[16];
+    if constexpr (INIT) {
         const float* src = a.amp + ((size_t)b * a.maxF + f0) * 201;
         for (int i = tid; i < VG * 201; i += VT) amps[i] = (i < nvalid * 201) ? src[i] : 0.0f;
-        if (INIT) {
-            const float* ps = a.phase0 + ((size_t)b * a.maxF + f0) * 201;
-            for (int i = tid; i < VG * 201; i += VT) xs[i] = (i < nvalid * 201) ? ps[i] : 0.0f;
+        const float* ps = a.phase0 + ((size_t)b * a.maxF + f0) * 201;
+        for (int i = tid; i < VG * 201; i += VT) xs[i] = (i < nvalid * 201) ? ps[i] : 0.0f;
+    } else {
+        const int g = min(tid / 13, VG - 1), k1 = tid - (tid / 13) * 13;
+        const bool live = tid < NROW && g < nvalid;
+        const float* src = a.amp + ((size_t)b * a.maxF + f0 + (live ? g : 0)) * 201;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            bool cj;
+            const int bin = vcfe::src_bin(live ? k1 : 0, k2, cj);
+            const float v = src[bin];
+            amr[k2] = live ? v : 0.0f;
         }
     }
     __syncthreads();
@@ -146,7 +158,7 @@ gl_iter400_kernel(GlArgs a) {
         for (int k2 = 0; k2 < 16; ++k2) {
             bool cj;
             const int bin = vcfe::src_bin(k1, k2, cj);
-            const float am = amps[g * 201 + bin];
+            const float am = INIT ? amps[g * 201 + bin] : amr[k2];
             float ur, ui;
             if (INIT) {
                 float s, c;
@@ -411,7 +423,7 @@ int vc_vocoder_plan_create(int32_t win_length, int32_t hop_length, int32_t n_fft
         (void)hipFree(p->d_tables); delete p;
         return vc::set_error(VC_ERR_HIP, "vocoder plan: hipMemcpy failed");
     }
-    p->smem400 = sizeof(float) * (400 + 416 + 2 * (VG * 13) * VA_STRIDE + VG * 201 + (size_t)p->span);
+    p->smem400 = sizeof(float) * (400 + 416 + 2 * (VG * 13) * VA_STRIDE + (size_t)p->span);
     p->smem400_init = sizeof(float) * (400 + 416 + 2 * (VG * 13) * VA_STRIDE + 2 * VG * 201);
     p->smem_gen = sizeof(float) * ((size_t)3 * N + 2 * VGG * p->nb + p->span_g);
     if (N != 400 && p->smem_gen > 160 * 1024) {
