@@ -646,6 +646,7 @@ struct WArgs {
     const void* XT;     // [Cin, ldxt], pointer at frame 0 (margin before it)
     int32_t ldxt, ldyt, Cin, M, T, n_groups;
     int32_t splits;     // frame range split over gridDim.z; > 1 => float atomics into a zeroed dW
+    int32_t xcd_tiles;  // > 0: 1-D grid, XCD-aware block -> (group, tile, split) mapping; tiles per XCD and split
     WGroup g[VC_GEMM_MAX_GROUPS];
 };
 
@@ -658,16 +659,44 @@ wgrad_kernel(WArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const WGroup grp = a.g[a.n_groups - 1 - (int)blockIdx.y];
+    // Block -> (group, tile, frame split).  Plain form: grid (tiles, groups, splits).  XCD-aware form
+    // (grouped filter-bank launches): consecutive workgroup ids go round-robin to the 8 XCDs, each
+    // with its own 4 MB L2, and every tile of a group streams the same dY^T rows -- so a group's
+    // tiles are all given to ONE XCD (groups dealt to XCDs in snake order of their size, which
+    // balances the tile counts), ordered split-major so that the blocks resident together read
+    // the same frames.  With the plain mapping each XCD saw a slice of every group and dY^T
+    // (210 MB for the decoder's step-2 bank) was re-fetched from HBM for each tile.
+    int gsel, tile, zsplit;
+    if (a.xcd_tiles > 0) {
+        const int xcd = blockIdx.x & 7;
+        int slot = blockIdx.x >> 3;
+        zsplit = slot / a.xcd_tiles;
+        slot -= zsplit * a.xcd_tiles;
+        gsel = -1; tile = 0;
+        for (int gi = 0; gi < a.n_groups; ++gi) {            // gi = rank by size (a.g is sorted ascending)
+            const int r16 = gi & 15;
+            if ((r16 < 8 ? r16 : 15 - r16) != xcd) continue;
+            const WGroup& gg = a.g[a.n_groups - 1 - gi];
+            const int tg = ((gg.taps * a.Cin + BM - 1) / BM) * ((gg.N + BN - 1) / BN);
+            if (slot < tg) { gsel = a.n_groups - 1 - gi; tile = slot; break; }
+            slot -= tg;
+        }
+        if (gsel < 0) return;
+    } else {
+        gsel = a.n_groups - 1 - (int)blockIdx.y;
+        tile = blockIdx.x;
+        zsplit = blockIdx.z;
+    }
+    const WGroup grp = a.g[gsel];
     const int R = grp.taps * a.Cin;
     const int ntn = (grp.N + BN - 1) / BN, ntr = (R + BM - 1) / BM;
-    if ((int)blockIdx.x >= ntr * ntn) return;            // groups have different tile counts
-    const int rt = blockIdx.x / ntn, nt = blockIdx.x - rt * ntn;
+    if (tile >= ntr * ntn) return;                       // groups have different tile counts
+    const int rt = tile / ntn, nt = tile - rt * ntn;
     const int r0 = rt * BM, n0 = nt * BN;
     const int Tn = a.T, M = a.M;
     const int nk_all = (M + BK - 1) / BK;
     const int per = (nk_all + a.splits - 1) / a.splits;
-    const int k_lo = (int)blockIdx.z * per, k_hi = min(nk_all, k_lo + per);
+    const int k_lo = zsplit * per, k_hi = min(nk_all, k_lo + per);
     const int nk = k_hi - k_lo;
     if (nk <= 0) return;
     const float* XT = reinterpret_cast<const float*>(a.XT);
@@ -938,12 +967,47 @@ extern "C" int vc_conv_wgrad(const vc_wgrad_desc* d, void* stream) {
     // CUs: split the frame range over gridDim.z until ~2 blocks per CU exist.  The caller zeroes dW
     // when it passes splits_allowed (atomic accumulation); the summation order is then not fixed.
     int splits = 1;
-    if (d->splits_allowed) {
-        const long blocks = (long)max_tiles * d->n_groups;
-        const int nk_all = (d->M + 31) / 32;
+    const long blocks = (long)max_tiles * d->n_groups;
+    const int nk_all = (d->M + 31) / 32;
+    if (d->splits_allowed)
         while (blocks * splits < 512 && splits * 2 <= 32 && nk_all / (splits * 2) >= 8) splits *= 2;
-    }
     wa.splits = splits;
+    wa.xcd_tiles = 0;
+    // Grouped launches with enough tiles to fill the chip: XCD-aware mapping (see wgrad_kernel).
+    // The groups arrive sorted by size (the kernel reads a.g[] back to front as "heaviest first").
+    bool sorted = d->n_groups >= 8;
+    for (int g = 1; g < d->n_groups && sorted; ++g) sorted = d->groups[g].taps >= d->groups[g - 1].taps;
+    const char* env = std::getenv("VC_WGRAD_XCD");
+    if (sorted && !(env && env[0] == '0')) {
+        long per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0;
+        for (int gi = 0; gi < d->n_groups; ++gi) {
+            const vc_wgrad_group& gg = d->groups[d->n_groups - 1 - gi];
+            const int r16 = gi & 15;
+            const long tg = (long)((gg.taps * d->Cin + 127) / 128) * ((gg.N + BN - 1) / BN);
+            per_xcd[r16 < 8 ? r16 : 15 - r16] += tg;
+            total += tg;
+        }
+        long mx = 0;
+        for (int x = 0; x < 8; ++x) mx = per_xcd[x] > mx ? per_xcd[x] : mx;
+        if (total >= 512 && mx > 0) {
+            // 64 blocks are resident per XCD; a frame split that lands the rounds on a whole number
+            // beats a ragged last round (atomics: only where the caller allows them)
+            int best = 1;
+            if (d->splits_allowed) {
+                double best_cost = 1e30;
+                for (int sp = 1; sp <= 8 && nk_all / sp >= 16; sp *= 2) {
+                    const double cost = (double)((mx * sp + 63) / 64) / sp * (1.0 + 0.02 * (sp - 1));
+                    if (cost < best_cost - 1e-9) { best_cost = cost; best = sp; }
+                }
+            }
+            wa.splits = best;
+            wa.xcd_tiles = (int)mx;
+            hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)(8 * mx * best)), dim3(GEMM_THREADS), lds_bytes(2),
+                               static_cast<hipStream_t>(stream), wa);
+            VC_HIP_CHECK(hipGetLastError());
+            return VC_OK;
+        }
+    }
     hipLaunchKernelGGL(wgrad_kernel, dim3(max_tiles, d->n_groups, splits), dim3(GEMM_THREADS), lds_bytes(2),
                        static_cast<hipStream_t>(stream), wa);
     VC_HIP_CHECK(hipGetLastError());
