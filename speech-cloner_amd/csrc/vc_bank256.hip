@@ -22,6 +22,7 @@
 // address of the LDS-direct loads (the LDS image of one wave instruction is linear), so the 16
 // lanes of a ds_read_b128 group hit 16 different bank groups.  SAME-padding zeros depend on
 // (output frame, tap) and are a per-lane select on the A fragment.
+#include <cstdlib>
 #include "vc_common.h"
 #include "vc_bank256.h"
 
@@ -52,8 +53,28 @@ bank256_kernel(Bank256Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
     const int wr = wid >> 2, wc = wid & 3;             // wave tile: rows wr*128.., cols wc*64..
-    const Bank256Pair pr = a.p[a.n_pairs - 1 - (int)blockIdx.y];   // widest pair first
-    const int m0 = blockIdx.x * (a.pool ? BM - 1 : BM);    // pooled output: tiles overlap by one frame
+    // Block -> (pair, row tile).  XCD-aware form (a.xcd_tiles = row tiles per pair): workgroup ids go
+    // round-robin to the 8 XCDs, so id & 7 names the XCD; pairs are dealt to XCDs in snake order of
+    // their width (balanced: rank x and rank 15 - x together), a pair's row tiles all run on one
+    // XCD and its weight stream (up to 4 MB) is fetched into that XCD's L2 once instead of eight times.
+    int psel, rt;
+    if (a.xcd_tiles > 0) {
+        const int xcd = blockIdx.x & 7;
+        int slot = blockIdx.x >> 3;
+        psel = -1; rt = 0;
+        for (int gi = 0; gi < a.n_pairs; ++gi) {               // gi = rank by width, widest first
+            const int r16 = gi & 15;
+            if ((r16 < 8 ? r16 : 15 - r16) != xcd) continue;
+            if (slot < a.xcd_tiles) { psel = a.n_pairs - 1 - gi; rt = slot; break; }
+            slot -= a.xcd_tiles;
+        }
+        if (psel < 0) return;
+    } else {
+        psel = a.n_pairs - 1 - (int)blockIdx.y;               // widest pair first
+        rt = blockIdx.x;
+    }
+    const Bank256Pair pr = a.p[psel];
+    const int m0 = rt * (a.pool ? BM - 1 : BM);            // pooled output: tiles overlap by one frame
     const int ntap = pr.taps0 + 1;                     // taps of the wider filter
     const int nslab = a.Cin >> 6;
     const int ntiles = nslab * ntap;
@@ -362,7 +383,21 @@ int vc_launch_bank256(const Bank256Args& a, hipStream_t st) {
         attr_done = true;
     }
     const int stride = a.pool ? BM - 1 : BM;
-    hipLaunchKernelGGL(bank256_kernel, dim3((a.M + stride - 1) / stride, a.n_pairs), dim3(NT), LDS_BYTES, st, a);
+    const int ntm = (a.M + stride - 1) / stride;
+    Bank256Args b = a;
+    const char* env = getenv("VC_BANK256_XCD");
+    b.xcd_tiles = (a.n_pairs >= 8 && !(env && env[0] == '0')) ? ntm : 0;
+    if (b.xcd_tiles > 0) {
+        int per_xcd = 0;                                   // pairs on the fullest XCD
+        for (int x = 0; x < 8; ++x) {
+            int c = 0;
+            for (int gi = 0; gi < a.n_pairs; ++gi) { const int r16 = gi & 15; c += ((r16 < 8 ? r16 : 15 - r16) == x); }
+            per_xcd = c > per_xcd ? c : per_xcd;
+        }
+        hipLaunchKernelGGL(bank256_kernel, dim3((unsigned)(8 * per_xcd * ntm)), dim3(NT), LDS_BYTES, st, b);
+    } else {
+        hipLaunchKernelGGL(bank256_kernel, dim3(ntm, a.n_pairs), dim3(NT), LDS_BYTES, st, b);
+    }
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }
