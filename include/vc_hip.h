@@ -375,6 +375,54 @@ int vc_highway_chain(const void* d_X, int32_t M, int32_t H, int32_t ldx, int32_t
                      const void* d_proj_packed, const float* d_proj_bias, int32_t n_proj, float* d_P, int32_t ldp,
                      void* stream);
 
+/* ---- the encoder's pre-recurrence chain in one launch -------------------------------------------
+ * encoder.py:101-107 up to the GRU: prenet (modules.py:274-295) -> conv1d_banks + bn + relu
+ * (modules.py:144-166) -> max_pooling1d (modules.py:331) -> conv1d k=3 + bn + relu -> conv1d k=3 + bn
+ * + residual (modules.py:334-340) -> highwaynet x n_highway (modules.py:342-345) -> the x-halves of
+ * the bidirectional GRU's cell matmuls (modules.py:346, 168-204), for the SHIPPED encoder shape
+ * (hp/encoder_cfg_d.json: 80 features, prenet 80 -> 40, 6 banks x 128 filters, GRU of 40 units; bf16
+ * weights, inference).  vc_cbhg_front_supported() says whether a shape takes this path; callers run
+ * the per-layer entry points (vc_conv_gemm, vc_highway_chain) otherwise -- same results within bf16
+ * rounding (different float32 summation order).
+ *
+ * Weights are handed over in MFMA fragment order, built with vc_mfma_pack from row-major bf16
+ * matrices W [rows, K] (row = output channel, K contiguous):
+ *   packed[(tile * nks + s) * 64 + lane][e] = W[32 tile + (lane & 31)][kmap(16 s + 8 (lane >> 5) + e)],
+ *   tile < ceil(rows / 32), s < nks = ceil(K / 16), zero outside W;
+ *   kmap = identity (chained = 0) or, for a layer that consumes the previous layer's result tile
+ *   straight from registers (chained = 1), kmap(16 s + 8 h + e) = 32 (s>>1) + 8 (2 (s&1) + (e>>2)) + 4 h + (e&3).
+ * Matrices (TF kernels transposed to [out, in]):
+ *   d_pk_dense1  [80, 80] plain;  d_pk_dense2 [40, 80] chained;
+ *   d_pk_bank    the 6 filters [128, 40 k] (K index = tap * 40 + channel), plain, concatenated k = 1..6;
+ *   d_pk_proj1   [40, 2304] with K re-ordered to (width k-1, 32-channel slice w, tap, 16-channel half s, 16):
+ *                column ((((k-1) * 4 + w) * 3 + tap) * 2 + s) * 16 + j  <-  conv1d_1 kernel[tap, (k-1) * 128 + 32 w + 16 s + j, :], plain;
+ *   d_pk_proj2   [40, 120] (K index = tap * 40 + channel), plain;
+ *   d_pk_highway[l] the paired [128, 40] matrix (rows 64 q .. +31 dense1 of units 32 q .., rows 64 q + 32 .. dense2), chained;
+ *   d_pk_gru     [240, 40] (rows: fw gates 80 | fw candidate 40 | bw gates 80 | bw candidate 40), chained.
+ * d_coef: ONE float32 array of vc_cbhg_front_coef_floats() (= 3232) values, every vector zero padded to its slot:
+ *   [0, 96) dense1 bias | [96, 160) dense2 bias | [160, 1184) bank scale | [1184, 2208) bank shift (folded batch
+ *   norm of the 768 bank channels) | [2208, 2272) conv1d_1 scale | [2272, 2336) shift | [2336, 2400) conv1d_2 scale |
+ *   [2400, 2464) shift | [2464, 2720) GRU bias (240) | [2720 + 128 l, +128) highway layer l biases, paired order.
+ * d_x [n_windows * T, ldx] float32 (x_f32 = 1) or bf16; d_xproj [n_windows * T, ldp] float32 receives
+ * columns [0, 240). */
+#define VC_CBHG_FRONT_MAX_HIGHWAY 4
+typedef struct vc_cbhg_front_desc {
+    const void* d_x;
+    int32_t x_f32, ldx;
+    int32_t n_windows, T;
+    int32_t n_features, prenet_units, width, n_banks, bank_filters, n_highway, gru_units;
+    const void *d_pk_dense1, *d_pk_dense2, *d_pk_bank, *d_pk_proj1, *d_pk_proj2, *d_pk_gru;
+    const void* d_pk_highway[VC_CBHG_FRONT_MAX_HIGHWAY];
+    const float* d_coef;
+    float* d_xproj;
+    int32_t ldp;
+} vc_cbhg_front_desc;
+int vc_mfma_pack(const void* d_W, int32_t rows, int32_t K, int32_t ldw, int32_t chained, void* d_packed, void* stream);
+int32_t vc_cbhg_front_coef_floats(void);
+int vc_cbhg_front_supported(int32_t n_features, int32_t prenet_units, int32_t width, int32_t n_banks,
+                            int32_t bank_filters, int32_t n_highway, int32_t gru_units, int32_t T);
+int vc_cbhg_front(const vc_cbhg_front_desc* desc, void* stream);
+
 /* ---- on-device feature cache -----------------------------------
  * dst[r, :] = src[index[r], :] for index[r] >= 0, else pad_row (zeros when d_pad_row is NULL).
  * Rows are row_bytes wide (multiple of 4).  Replaces the h5py slicing + np.array stacking of

@@ -54,6 +54,21 @@ class GemmDesc(C.Structure):
                 ('epi_pool', C.c_int32)]
 
 
+CBHG_FRONT_MAX_HIGHWAY = 4
+
+
+class CbhgFrontDesc(C.Structure):
+    """struct vc_cbhg_front_desc (include/vc_hip.h)."""
+    _fields_ = [('d_x', C.c_void_p), ('x_f32', C.c_int32), ('ldx', C.c_int32), ('n_windows', C.c_int32), ('T', C.c_int32),
+                ('n_features', C.c_int32), ('prenet_units', C.c_int32), ('width', C.c_int32), ('n_banks', C.c_int32),
+                ('bank_filters', C.c_int32), ('n_highway', C.c_int32), ('gru_units', C.c_int32),
+                ('d_pk_dense1', C.c_void_p), ('d_pk_dense2', C.c_void_p), ('d_pk_bank', C.c_void_p),
+                ('d_pk_proj1', C.c_void_p), ('d_pk_proj2', C.c_void_p), ('d_pk_gru', C.c_void_p),
+                ('d_pk_highway', C.c_void_p * CBHG_FRONT_MAX_HIGHWAY),
+                ('d_coef', C.c_void_p),
+                ('d_xproj', C.c_void_p), ('ldp', C.c_int32)]
+
+
 class WgradGroup(C.Structure):
     """struct vc_wgrad_group (include/vc_hip.h)."""
     _fields_ = [('d_dYT', C.c_void_p), ('d_dW', C.c_void_p), ('N', C.c_int32), ('taps', C.c_int32),
@@ -117,6 +132,10 @@ _SIGS = {
     'vc_highway_pack': (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     'vc_highway_chain': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(_P), C.POINTER(_P), _P, C.c_int32,
                                    _P, _P, C.c_int32, _P, C.c_int32, _P]),
+    'vc_mfma_pack': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    'vc_cbhg_front_coef_floats': (C.c_int32, []),
+    'vc_cbhg_front_supported': (C.c_int, [C.c_int32] * 8),
+    'vc_cbhg_front': (C.c_int, [C.POINTER(CbhgFrontDesc), _P]),
     'vc_gather_rows': (C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     'vc_vocoder_plan_create': (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(_P)]),
     'vc_vocoder_plan_destroy': (None, [_P]),

@@ -498,13 +498,18 @@ int launch_mfma(const GruArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 // direction), no LDS and no barriers.  Lane j owns hidden unit j: its three weight columns
 // (r_j, u_j, c_j: 3H f32 registers) and h_j.  h is broadcast to the wave one element at a time
 // with v_readlane (the value becomes a scalar operand of the FMAs).
+// WPB waves (= sequences) per workgroup, one per SIMD of a CU: as single-wave workgroups the 2 * n_seq
+// waves were dealt to as many CUs, and a CU that holds one of them for 400 steps cannot take a
+// workgroup of the register-filling MFMA kernels of the other streams (half the chip at 64 windows).
+constexpr int GRU_WAVE_WPB = 4;
 template <int H, typename WT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64 * GRU_WAVE_WPB)
 gru_wave_kernel(GruArgs a) {
     static_assert(H <= 64 && H % 4 == 0, "one lane per hidden unit, unrolled by 4");
     constexpr int H3 = 3 * H;
-    const int lane = threadIdx.x;
-    const int seq = blockIdx.x, dir = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int seq = blockIdx.x * GRU_WAVE_WPB + (threadIdx.x >> 6), dir = blockIdx.y;
+    if (seq >= a.n_seq) return;
     const bool act = lane < H;
     const int j = act ? lane : 0;
     const WT* W = reinterpret_cast<const WT*>(a.Wh[dir]);
@@ -648,8 +653,9 @@ int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw,
     // (H = 128 runs 256 threads: four fat waves beat sixteen thin ones, the step is barrier-bound)
     if (w_dtype == VC_F32 && H == 128) return launch_resident<128, float, 1024>(a, d_workspace, workspace_bytes, st);
     if (H == 40) {                                      // the shipped encoder (hp/encoder_cfg_d.json)
-        if (w_dtype == VC_F32) hipLaunchKernelGGL((gru_wave_kernel<40, float>), grid, dim3(64), 0, st, a);
-        else hipLaunchKernelGGL((gru_wave_kernel<40, __bf16>), grid, dim3(64), 0, st, a);
+        const dim3 gw((n_seq + GRU_WAVE_WPB - 1) / GRU_WAVE_WPB, 2);
+        if (w_dtype == VC_F32) hipLaunchKernelGGL((gru_wave_kernel<40, float>), gw, dim3(64 * GRU_WAVE_WPB), 0, st, a);
+        else hipLaunchKernelGGL((gru_wave_kernel<40, __bf16>), gw, dim3(64 * GRU_WAVE_WPB), 0, st, a);
         VC_HIP_CHECK(hipGetLastError());
         return VC_OK;
     }

@@ -119,10 +119,9 @@ class encoder_spec_phn:
                             'is evaluated through exec_train_step / exec_calc_metrics')
         st = self.store
         with modules.variable_store(st), modules.variable_scope(self._scope):
-            xin = modules.convert(x, st.dtype)
-            prenet_out = prenet(xin, None, self._embed_size, c['dropout_rate'], False, scope="prenet")
-            cbhg_out = CBHG(prenet_out, self._embed_size, c['num_conv_banks'], c['num_highwaynet_blocks'],
-                            c['dropout_rate'], False, scope="CBHG", use_Cudnn=c['use_Cudnn'], use_lstm=c['use_lstm'])
+            cbhg_out = modules.prenet_CBHG(x, self._embed_size, c['num_conv_banks'], c['num_highwaynet_blocks'],
+                                           c['dropout_rate'], False, prenet_scope="prenet", scope="CBHG",
+                                           use_Cudnn=c['use_Cudnn'], use_lstm=c['use_lstm'])
             y_logits = modules.dense(cbhg_out, c['n_output'], None, name="y_logits", out_f32=True)
         y_pred, y_cls = modules.softmax_argmax(y_logits)
         out = {'CBHG_out': cbhg_out, 'y_logits': y_logits, 'y_pred': y_pred, 'y_pred_class': y_cls}

@@ -547,6 +547,97 @@ def CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dro
     return output
 
 
+def _cbhg_front(x, E, num_conv_banks, num_highwaynet_blocks, prenet_scope, scope):
+    """The fused launch of prenet_CBHG: features [N, T, C] -> (xproj float32 [N*T, 6H], recurrent weights)."""
+    torch = _torch()
+    store = _store()
+    N_, T_, Cx = x.shape
+    Cw, H = E // 2, E // 2
+    with variable_scope(prenet_scope):
+        bt1, b1 = _prep_dense(store, _scope('dense1'), Cx, E)
+        bt2, b2 = _prep_dense(store, _scope('dense2'), E, Cw)
+        psc = _scope()
+    with variable_scope(scope):
+        csc = _scope()
+        banks = []
+        with variable_scope('conv1d_banks'):
+            for k in range(1, num_conv_banks + 1):
+                with variable_scope('conv1d' if k == 1 else 'num_{}/conv1d'.format(k)):
+                    banks.append(_prep_conv(store, _scope(), k, Cw, 128))
+            bs, bsh = _prep_bn(store, _scope('bn'), 128 * num_conv_banks)
+        with variable_scope('conv1d_1'):
+            _prep_conv(store, _scope(), 3, 128 * num_conv_banks, Cw)
+            k1 = store.vars[_scope() + '/conv1d/kernel']
+        p1s, p1b = _prep_bn(store, _scope('conv1d_1'), Cw)
+        with variable_scope('conv1d_2'):
+            bt_p2 = _prep_conv(store, _scope(), 3, Cw, Cw)
+        p2s, p2b = _prep_bn(store, _scope('conv1d_2'), Cw)
+        hws = [_prep_highway(store, _scope('highwaynet_{}'.format(i)), Cw) for i in range(num_highwaynet_blocks)]
+        btx, bx, wh_fw, wh_bw = _prep_gru(store, _scope('gru'), Cw, H)
+
+    def build():
+        K_ = num_conv_banks
+        coef = torch.zeros((_vc.lib().vc_cbhg_front_coef_floats(),), dtype=torch.float32, device=store.device)
+        for off, v in ((0, b1), (96, b2), (160, bs), (1184, bsh), (2208, p1s), (2272, p1b), (2336, p2s), (2400, p2b),
+                       (2464, bx)) + tuple((2720 + 128 * i, hb) for i, (_, hb) in enumerate(hws)):
+            coef[off:off + v.numel()] = v
+        w1 = k1.reshape(3, K_, 4, 2, 16, Cw).permute(5, 1, 2, 0, 3, 4).reshape(Cw, 3 * 128 * K_).to(store.dtype)
+        return dict(
+            d1=_mfma_pack(bt1, E, Cx, 0), d2=_mfma_pack(bt2, Cw, E, 1),
+            bank=torch.cat([_mfma_pack(b, 128, (k + 1) * Cw, 0) for k, b in enumerate(banks)]),
+            p1=_mfma_pack(w1, Cw, 3 * 128 * K_, 0), p2=_mfma_pack(bt_p2, Cw, 3 * Cw, 0),
+            hw=[_mfma_pack(bt, bt.shape[0], Cw, 1) for bt, _ in hws], gx=_mfma_pack(btx, 6 * H, Cw, 1),
+            coef=coef)
+    pk = store.cached(('cbhg_front', psc, csc), build)
+    x = x.contiguous()
+    xproj = torch.empty((N_ * T_, 6 * H), dtype=torch.float32, device=x.device)
+    d = _vc.CbhgFrontDesc()
+    d.d_x, d.x_f32, d.ldx, d.n_windows, d.T = x.data_ptr(), int(x.dtype == torch.float32), Cx, N_, T_
+    d.n_features, d.prenet_units, d.width, d.n_banks, d.bank_filters = Cx, E, Cw, num_conv_banks, 128
+    d.n_highway, d.gru_units = num_highwaynet_blocks, H
+    d.d_pk_dense1, d.d_pk_dense2, d.d_pk_bank = pk['d1'].data_ptr(), pk['d2'].data_ptr(), pk['bank'].data_ptr()
+    d.d_pk_proj1, d.d_pk_proj2, d.d_pk_gru = pk['p1'].data_ptr(), pk['p2'].data_ptr(), pk['gx'].data_ptr()
+    for i in range(num_highwaynet_blocks):
+        d.d_pk_highway[i] = pk['hw'][i].data_ptr()
+    d.d_coef = pk['coef'].data_ptr()
+    d.d_xproj, d.ldp = xproj.data_ptr(), 6 * H
+    _vc.check(_vc.lib().vc_cbhg_front(C.byref(d), _vc.current_stream()))
+    return xproj, H, wh_fw, wh_bw
+
+
+def _mfma_pack(W, rows, K, chained):
+    """Row-major bf16 matrix [rows, >= K] -> MFMA fragment order (vc_mfma_pack, include/vc_hip.h)."""
+    torch = _torch()
+    W = W.contiguous()
+    out = torch.empty(((rows + 31) // 32) * ((K + 15) // 16) * 512, dtype=torch.bfloat16, device=W.device)
+    _vc.check(_vc.lib().vc_mfma_pack(W.data_ptr(), rows, K, W.shape[1], int(chained), out.data_ptr(), _vc.current_stream()))
+    return out
+
+
+def prenet_CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dropout_rate=0.5, is_training=True,
+                prenet_scope="prenet", scope="CBHG", use_Cudnn=False, use_lstm=False, in_features=None):
+    """prenet (modules.py:274-295) followed by CBHG (modules.py:323-356), as encoder.py:101-107 and
+    decoder.py:100-125 / 134-153 call them.  The shipped encoder shape in bf16 runs everything up to the
+    recurrence as ONE launch (vc_cbhg_front: the layers are 40 channels wide, launch- and HBM-latency
+    bound one by one); every other shape is prenet() + CBHG().  ``inputs`` may be float32 there (the
+    conversion is part of the launch).  VC_CBHG_FRONT=0 switches the fused form off (A/B)."""
+    torch = _torch()
+    store = _store()
+    x = _as3(inputs)
+    N_, T_, Cx = x.shape
+    cin = Cx if in_features is None else in_features
+    E = embed_size
+    fused = (not is_training and not use_lstm and store.dtype == torch.bfloat16 and cin == Cx
+             and os.environ.get('VC_CBHG_FRONT', '1') != '0'
+             and bool(_vc.lib().vc_cbhg_front_supported(Cx, E, E // 2, num_conv_banks, 128, num_highwaynet_blocks, E // 2, T_)))
+    if not fused:
+        pre = prenet(convert(x, store.dtype), None, E, dropout_rate, is_training, scope=prenet_scope, in_features=in_features)
+        return CBHG(pre, E, num_conv_banks, num_highwaynet_blocks, dropout_rate, is_training, scope=scope,
+                    use_Cudnn=use_Cudnn, use_lstm=use_lstm)
+    xproj, H, wh_fw, wh_bw = _cbhg_front(x, E, num_conv_banks, num_highwaynet_blocks, prenet_scope, scope)
+    return _gru_recurrence(xproj, N_, T_, H, wh_fw, wh_bw)
+
+
 def create_stage_variables(store, scope, in_features, embed_size, num_conv_banks, num_highwaynet_blocks, n_output):
     """Create (if absent) every variable of one prenet -> CBHG -> dense(n_output) stage under
     ``scope`` with TensorFlow's default initialisers, in graph order, WITHOUT launching kernels

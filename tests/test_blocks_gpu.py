@@ -334,3 +334,46 @@ def test_gemm_argument_errors_are_reported():
     with modules.variable_store(st), modules.variable_scope('bad'):
         with pytest.raises((_vc.VCError, ValueError)):
             modules.conv1d(x, filters=8, size=3, scope='cv')
+
+
+@pytest.mark.parametrize('N,T,L,f32_in,mi', [(3, 400, 1, True, '2'), (2, 250, 2, False, '2'), (1, 97, 0, True, '2'),
+                                              (5, 400, 1, True, '4'), (2, 123, 3, False, '4'), (1, 8, 1, True, '2')])
+def test_encoder_front_single_launch(N, T, L, f32_in, mi, monkeypatch):
+    """prenet + CBHG of the shipped encoder shape as ONE launch up to the recurrence (vc_cbhg_front) against
+    the per-layer launches and the oracle: window edges (SAME padding of every convolution, the pool's last
+    frame), tiles that do not divide the window, 0..3 highway layers, float32 / bf16 features, both tile
+    heights, NaN-poisoned LDS."""
+    import modules
+    from conftest import poison_gpu_state
+    rng = np.random.RandomState(T + L)
+    st = _store('bfloat16')
+    x = torch.from_numpy((0.5 * rng.standard_normal((N, T, 80))).astype(np.float32)).cuda()
+    xin = x if f32_in else modules.convert(x, st.dtype)
+    args = dict(embed_size=80, num_conv_banks=6, num_highwaynet_blocks=L, dropout_rate=0.4, is_training=False)
+    with modules.variable_store(st), modules.variable_scope('e'):
+        monkeypatch.setenv('VC_CBHG_FRONT', '0')
+        modules.prenet_CBHG(xin, **args)                                   # creates the variables
+        for n, v in list(st.vars.items()):                                   # non-trivial norms / biases
+            if n.endswith('gamma') or n.endswith('moving_variance'):
+                st.assign(n, rng.uniform(0.5, 1.5, tuple(v.shape)).astype(np.float32))
+            elif n.endswith('beta') or n.endswith('moving_mean') or n.endswith('bias'):
+                st.assign(n, rng.uniform(-0.3, 0.3, tuple(v.shape)).astype(np.float32))
+        y_ref = modules.prenet_CBHG(xin, **args)
+        monkeypatch.setenv('VC_CBHG_FRONT', '1')
+        monkeypatch.setenv('VC_CBHG_FRONT_MI', mi)
+        assert modules._vc.lib().vc_cbhg_front_supported(80, 80, 40, 6, 128, L, 40, T)
+        poison_gpu_state()
+        y = modules.prenet_CBHG(xin, **args)
+        xp = modules._cbhg_front(xin, 80, 6, L, 'prenet', 'CBHG')[0]
+        poison_gpu_state()
+        y2 = modules.prenet_CBHG(xin, **args)
+    torch.cuda.synchronize()
+    assert y.shape == (N, T, 80) and not torch.isnan(y.float()).any() and not torch.isnan(xp).any()
+    assert torch.equal(y, y2)                                               # deterministic (fixed-order partial sums)
+    # same roundings as the per-layer path, float32 sums in another order
+    d = (y.float() - y_ref.float()).abs()
+    assert d.max().item() < 2e-2 and d.mean().item() < 2e-4, (d.max().item(), d.mean().item())
+    cast = lambda t: t.float().bfloat16().double()
+    w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
+    ref = mo.cbhg(mo.prenet(cast(x.cpu()), w, 'e/prenet'), w, 'e/CBHG', 6, L)
+    _close(y, ref, TOL['bfloat16'], 'fused encoder front T=%d L=%d' % (T, L))

@@ -11,6 +11,11 @@ if len(sys.argv) > 2 and sys.argv[1] == '--parse':
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
     marks = [i for i, r in enumerate(rows) if 'fill_kernel' in r['Kernel_Name']]
     a, b = marks[-2], marks[-1]
+    if '--list' in sys.argv:
+        for r in rows[a + 1:b]:
+            d = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3
+            print('%8.1f us  grid %-9s wg %-5s lds %-7s %s' % (d, r.get('Grid_Size', '?'), r.get('Workgroup_Size', '?'),
+                                                          r.get('LDS_Block_Size', '?'), r['Kernel_Name'][:90]))
     agg = collections.OrderedDict()
     for r in rows[a + 1:b]:
         n = r['Kernel_Name'][:70]
