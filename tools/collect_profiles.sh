@@ -28,7 +28,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 names = {'bank256_kernel': 'bank256_kernel_bf16_step2', 'conv_kernelIDF16bLi0': 'conv_kernel_bf16_pro0', 'conv_kernelIDF16bLi1': 'conv_kernel_bf16_proj1_step2',
          'gru_resident_kernelILi256': 'gru_resident_256', 'fe_power400': 'fe_power400_kernel',
          'fe_finalize': 'fe_finalize_kernel', 'fe_abssum': 'fe_abssum_kernel',
-         'gl_iter400_kernel<false>': 'gl_iter400_kernel'}
+         'gl_iter400_kernel<false>': 'gl_iter400_kernel', 'cbhg_small_kernel': 'cbhg_small_kernel'}
 for f in glob.glob('$O/pmc_*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         for k, v in names.items():

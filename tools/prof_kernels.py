@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Runs the dominant kernels of the hot path a few times each, stand-alone, so rocprofv3 (kernel
-trace or --pmc passes) sees clean dispatches:  python tools/prof_kernels.py [bank|proj1|gru|frontend|vocoder|all]
+trace or --pmc passes) sees clean dispatches:  python tools/prof_kernels.py [bank|proj1|gru|encfront|frontend|vocoder|all]
 
 Shapes = the bench's full workload (64 windows x 400 frames, decoder step 2, bf16; front-end on
 32 x 4 s).  Prints the algorithmic bytes / FLOPs per launch used by bench.py's roofline."""
@@ -30,6 +30,11 @@ with modules.variable_store(st), modules.variable_scope('decoder'), modules.vari
     if what in ('gru', 'all'):
         for _ in range(reps):
             modules.gru(pre, num_units=256, bidirection=True)
+if what in ('encfront', 'all'):
+    with modules.variable_store(st), modules.variable_scope('encoder'):
+        xe = torch.rand(W, T, 80, device='cuda') * 0.4 - 0.2
+        for _ in range(reps):
+            modules._cbhg_front(xe, 80, 6, 1, 'prenet', 'CBHG')
 if what in ('frontend', 'all'):
     wav = bench.synth_audio(32, 64000, 0).cuda()
     out = None
@@ -44,4 +49,5 @@ print('bank  : %.4g FLOP/launch ; operands: X %d B + W %d B, out %d B' % (
     2.0 * 256 * 128 * 528 * W * T, W * T * 256 * 2, 256 * 128 * 528 * 2, W * T * 4096 * 2))
 print('proj1 : %.4g FLOP/launch ; in %d B (x3 taps x2 pool via L2), W %d B, out %d B' % (
     2.0 * 3 * 4096 * 256 * W * T, W * T * 4096 * 2, 3 * 4096 * 256 * 2, W * T * 256 * 2))
+print('encfront: %.4g FLOP/launch ; in %d B, out %d B' % (2.0 * 226880 * W * T, W * T * 80 * 4, W * T * 240 * 4))
 print('front : %d B/launch algorithmic (1,764 B/frame x 25,632 frames)' % (1764 * 25632))
