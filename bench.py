@@ -193,6 +193,9 @@ def bench_full(args, rank, world):
             with torch.cuda.stream(st_):
                 xi = x[i:i + args.window_batch].contiguous()
                 xi.record_stream(st_)
+                copied = torch.cuda.Event()
+                copied.record(st_)
+                main.wait_event(copied)                # the next step's front-end overwrites fe_out
                 o = dec.forward(xi)
                 res[(i, chunk_no[0] % (2 * len(streams)))] = (o['y_mel'], o['y_stft'], o['y_phn'])
 

@@ -17,7 +17,9 @@ struct Bank256Args {
     int32_t act;
     void* C;
     int32_t ldc, n_pairs;
-    int32_t xcd_tiles;    // > 0: 1-D grid with the XCD-aware block -> (pair, row tile) mapping; = row tiles per pair
+    int32_t xcd_tiles;    // > 0: 1-D grid with the XCD-aware block -> (pair, row tile) mapping (set by the launcher)
+    // per XCD (workgroup id & 7) up to 4 segments of work, walked in order: row tiles [first, first + count) of a pair
+    int16_t seg_pair[8][4], seg_first[8][4], seg_count[8][4];
     int32_t pool;         // store max(y[t], y[t+1]) per window: row tiles advance by 255 frames
     int32_t dbg;          // measurement hook (VC_BANK256_DBG): 1 = skip the K loop, 2 = skip the stores, 4 = no loads inside the K loop (wrong results)
     Bank256Pair p[16];

@@ -53,20 +53,19 @@ bank256_kernel(Bank256Args a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
     const int wr = wid >> 2, wc = wid & 3;             // wave tile: rows wr*128.., cols wc*64..
-    // Block -> (pair, row tile).  XCD-aware form (a.xcd_tiles = row tiles per pair): workgroup ids go
-    // round-robin to the 8 XCDs, so id & 7 names the XCD; pairs are dealt to XCDs in snake order of
-    // their width (balanced: rank x and rank 15 - x together), a pair's row tiles all run on one
-    // XCD and its weight stream (up to 4 MB) is fetched into that XCD's L2 once instead of eight times.
+    // Block -> (pair, row tile).  XCD-aware form: workgroup ids go round-robin to the 8 XCDs, so id & 7
+    // names the XCD; the launcher gives every XCD a short list of (pair, row-tile range) segments so that a
+    // pair's weight stream (up to 4 MB) is fetched into one or two L2s instead of eight (see vc_launch_bank256).
     int psel, rt;
     if (a.xcd_tiles > 0) {
         const int xcd = blockIdx.x & 7;
         int slot = blockIdx.x >> 3;
         psel = -1; rt = 0;
-        for (int gi = 0; gi < a.n_pairs; ++gi) {               // gi = rank by width, widest first
-            const int r16 = gi & 15;
-            if ((r16 < 8 ? r16 : 15 - r16) != xcd) continue;
-            if (slot < a.xcd_tiles) { psel = a.n_pairs - 1 - gi; rt = slot; break; }
-            slot -= a.xcd_tiles;
+#pragma unroll
+        for (int sg = 0; sg < 4; ++sg) {
+            const int cnt = a.seg_count[xcd][sg];
+            if (psel < 0 && slot < cnt) { psel = a.seg_pair[xcd][sg]; rt = a.seg_first[xcd][sg] + slot; }
+            slot -= cnt;
         }
         if (psel < 0) return;
     } else {
@@ -386,15 +385,47 @@ int vc_launch_bank256(const Bank256Args& a, hipStream_t st) {
     const int ntm = (a.M + stride - 1) / stride;
     Bank256Args b = a;
     const char* env = getenv("VC_BANK256_XCD");
-    b.xcd_tiles = (a.n_pairs >= 8 && !(env && env[0] == '0')) ? ntm : 0;
+    b.xcd_tiles = (a.n_pairs >= 8 && a.n_pairs <= 16 && ntm < 32000 && !(env && env[0] == '0')) ? ntm : 0;
     if (b.xcd_tiles > 0) {
-        int per_xcd = 0;                                   // pairs on the fullest XCD
+        // Work lists per XCD.  Cost of a row tile of pair p ~ (wider taps) * slabs * 1.3 us + 10 us, 32 CUs per
+        // XCD take tiles in list order.  One pair per XCD pairing (rank x with rank 15 - x, whole pairs) balances
+        // the totals but quantises badly: 101 heavy tiles on 32 CUs are 3.2 rounds, and the XCD holding ranks 7
+        // and 8 runs 6.3 rounds of equal medium tiles -- the model (and the kernel) lose 14 % to those tails.
+        // With 16 pairs every pair is therefore split over TWO XCDs and every XCD gets halves of four pairs: one
+        // heavy, two medium, one light (ranks s, 7 - s, 8 + s, 15 - s), heaviest first, so short tiles fill the
+        // tail: 5 % over the ideal in the model, at two L2 fetches per weight tile instead of one (eight without
+        // this mapping).  VC_BANK256_XCD=1 selects the whole-pair form (A/B).
+        for (int x = 0; x < 8; ++x)
+            for (int sg = 0; sg < 4; ++sg) b.seg_pair[x][sg] = b.seg_first[x][sg] = b.seg_count[x][sg] = 0;
+        const bool split = a.n_pairs == 16 && !(env && env[0] == '1');
+        int max_slots = 0;
         for (int x = 0; x < 8; ++x) {
-            int c = 0;
-            for (int gi = 0; gi < a.n_pairs; ++gi) { const int r16 = gi & 15; c += ((r16 < 8 ? r16 : 15 - r16) == x); }
-            per_xcd = c > per_xcd ? c : per_xcd;
+            int slots = 0;
+            if (split) {
+                const int s4 = x >> 1, half = x & 1;
+                const int ranks[4] = {s4, 7 - s4, 8 + s4, 15 - s4};              // by width, widest first
+                const int h0 = (ntm + 1) / 2;
+                for (int sg = 0; sg < 4; ++sg) {
+                    b.seg_pair[x][sg] = (int16_t)(a.n_pairs - 1 - ranks[sg]);
+                    b.seg_first[x][sg] = (int16_t)(half ? h0 : 0);
+                    b.seg_count[x][sg] = (int16_t)(half ? ntm - h0 : h0);
+                    slots += b.seg_count[x][sg];
+                }
+            } else {
+                int sg = 0;
+                for (int gi = 0; gi < a.n_pairs; ++gi) {                        // snake: rank x and 15 - x together
+                    const int r16 = gi & 15;
+                    if ((r16 < 8 ? r16 : 15 - r16) != x) continue;
+                    b.seg_pair[x][sg] = (int16_t)(a.n_pairs - 1 - gi);
+                    b.seg_first[x][sg] = 0;
+                    b.seg_count[x][sg] = (int16_t)ntm;
+                    slots += ntm;
+                    ++sg;
+                }
+            }
+            max_slots = slots > max_slots ? slots : max_slots;
         }
-        hipLaunchKernelGGL(bank256_kernel, dim3((unsigned)(8 * per_xcd * ntm)), dim3(NT), LDS_BYTES, st, b);
+        hipLaunchKernelGGL(bank256_kernel, dim3((unsigned)(8 * max_slots)), dim3(NT), LDS_BYTES, st, b);
     } else {
         hipLaunchKernelGGL(bank256_kernel, dim3(ntm, a.n_pairs), dim3(NT), LDS_BYTES, st, b);
     }

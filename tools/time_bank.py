@@ -37,8 +37,9 @@ if d.max().item() > 0:
 fl = 2.0 * Cin * 128 * 528 * W * T
 print('conv_kernel  %.4f ms  %.1f TFLOP/s' % (ms0, fl / ms0 / 1e9))
 print('bank256      %.4f ms  %.1f TFLOP/s' % (ms1, fl / ms1 / 1e9))
-os.environ['VC_BANK256_XCD'] = '0'
-with modules.variable_store(st), modules.variable_scope('d'):
-    out2 = modules.conv1d_banks(pre, K=32, is_training=False).float()
-    ms2 = bench.time_events(lambda: modules.conv1d_banks(pre, K=32, is_training=False), 20)
-print('bank256 (plain block order) %.4f ms  %.1f TFLOP/s; equal to XCD-aware: %s' % (ms2, fl / ms2 / 1e9, bool(torch.equal(out, out2))))
+for mode, what in (('1', 'whole pairs per XCD'), ('0', 'plain block order'), ('', 'pairs split over two XCDs (default)')):
+    os.environ['VC_BANK256_XCD'] = mode
+    with modules.variable_store(st), modules.variable_scope('d'):
+        out2 = modules.conv1d_banks(pre, K=32, is_training=False).float()
+        ms2 = bench.time_events(lambda: modules.conv1d_banks(pre, K=32, is_training=False), 20)
+    print('bank256 (%s) %.4f ms  %.1f TFLOP/s; equal to default: %s' % (what, ms2, fl / ms2 / 1e9, bool(torch.equal(out, out2))))
