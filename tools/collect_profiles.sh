@@ -18,6 +18,9 @@ for W in full frontend train vocoder; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$W -- python3 $R/bench.py --workload $W $EXTRA > $O/trace_$W.log 2>&1
   cp $O/trace_$W/*/*kernel_stats.csv $O/${W}_kernel_stats.csv 2>/dev/null
 done
+# the roofline kernel alone (bench.py's rocprof average mixes the step-1 and step-2 filter banks under one name)
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bank -- python3 $R/tools/prof_kernels.py bank > $O/trace_bank.log 2>&1
+cp $O/trace_bank/*/*kernel_stats.csv $O/bank_step2_kernel_stats.csv 2>/dev/null
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr " " "_" | cut -c1-20)
   timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$N -- python3 $R/tools/prof_kernels.py all > $O/pmc_$N.log 2>&1
