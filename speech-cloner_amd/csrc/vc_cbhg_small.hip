@@ -435,6 +435,117 @@ cbhg_small_kernel(CbhgSmallArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// prenet (modules.py:274-295) of the decoder stages as one launch: relu(relu(x W1 + b1) W2 + b2), bf16.
+// As two dense launches the 512- (256-) wide intermediate made an HBM round trip and each short-K GEMM paid
+// its per-block prologue / epilogue (27 + 68 us per step for 13 GFLOP).  Here a wave carries 32 frames
+// through both layers in registers (layer 2's weights in the chained K order, see above) and only the
+// output tile goes through a wave-private LDS tile for whole-row stores.  Every weight fragment is used for
+// ONE MFMA per wave, so the launch is bound by the L2 -> CU weight stream (0.34 MB per wave), not by MFMA.
+struct PrenetArgs {
+    const __bf16* X; int32_t M, ldx;
+    const bf16x8 *pk1, *pk2;
+    const float *b1, *b2;
+    __bf16* Y; int32_t ldy;
+};
+
+template <int CINP, int U1, int U2>
+__global__ void __launch_bounds__(256, U1 <= 256 ? 2 : 1)
+prenet_chain_kernel(PrenetArgs a) {
+    static_assert(CINP % 16 == 0 && U1 % 32 == 0 && U2 % 32 == 0, "shape");
+    constexpr int KS1 = CINP / 16, NT1 = U1 / 32, KS2 = U1 / 16, NT2 = U2 / 32;
+    constexpr int RING = 8, PITCH = U2 * 2 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * 128 + 32 * w;
+    const int row = min(m0 + li, a.M - 1);
+    char* const tile = smem + w * 32 * PITCH;
+
+    bf16x8 xb[KS1];
+    {
+        const __bf16* xr = a.X + (size_t)row * a.ldx + 8 * lh;
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) xb[s] = *reinterpret_cast<const bf16x8*>(xr + 16 * s);
+    }
+    // ---- layer 1: fragments stream through a RING-deep register ring, flat index f = tile * KS1 + k-step
+    bf16x4 y1[NT1][4];
+    {
+        const bf16x8* p1 = a.pk1 + lane;
+        bf16x8 ring[RING];
+#pragma unroll
+        for (int f = 0; f < RING; ++f) ring[f] = p1[(f < NT1 * KS1 ? f : NT1 * KS1 - 1) * 64];
+#pragma unroll
+        for (int tl = 0; tl < NT1; ++tl) {
+            f32x16 acc = zero16();
+#pragma unroll
+            for (int s = 0; s < KS1; ++s) {
+                const int f = tl * KS1 + s;
+                const bf16x8 wf = ring[f % RING];
+                if (f + RING < NT1 * KS1) ring[f % RING] = p1[(f + RING) * 64];
+                acc = mfma(wf, xb[s], acc);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b1 + 32 * tl + 8 * q + 4 * lh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) y1[tl][q][e] = (__bf16)fmaxf(acc[4 * q + e] + bb[e], 0.0f);
+            }
+        }
+    }
+    // ---- layer 2: one output tile per (rolled) iteration, K fully unrolled (the operand is a register array)
+    {
+        const bf16x8* p2 = a.pk2 + lane;
+        bf16x8 ring[RING];
+#pragma unroll
+        for (int f = 0; f < RING; ++f) ring[f] = p2[f * 64];
+#pragma unroll 1
+        for (int tl = 0; tl < NT2; ++tl) {
+            f32x16 acc = zero16();
+            const bf16x8* pt = p2 + (size_t)tl * KS2 * 64;
+            const bool more = tl + 1 < NT2;
+#pragma unroll
+            for (int s = 0; s < KS2; ++s) {
+                const bf16x8 wf = ring[s % RING];
+                // refill from this tile's stream, then from the next tile's first steps (clamped at the very end)
+                const int nf = s + RING;
+                ring[s % RING] = pt[(nf < KS2 || more ? nf : KS2 - 1) * 64];
+                acc = mfma(wf, chain<NT1>(y1, s), acc);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b2 + 32 * tl + 8 * q + 4 * lh);
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)fmaxf(acc[4 * q + e] + bb[e], 0.0f);
+                *reinterpret_cast<bf16x4*>(tile + li * PITCH + (32 * tl + 8 * q + 4 * lh) * 2) = o;
+            }
+        }
+    }
+    wave_lds_fence();
+    // ---- the wave's 32 x U2 tile -> global, 16 bytes per lane, whole rows
+    constexpr int CPR = U2 / 8;                        // 16-byte chunks per row
+    for (int idx = lane; idx < 32 * CPR; idx += 64) {
+        const int r = idx / CPR, c = idx - r * CPR;
+        if (m0 + r < a.M)
+            *reinterpret_cast<bf16x8*>(a.Y + (size_t)(m0 + r) * a.ldy + c * 8) = *reinterpret_cast<const bf16x8*>(tile + r * PITCH + c * 16);
+    }
+}
+
+template <int CINP, int U1, int U2> int launch_prenet_chain(const PrenetArgs& a, hipStream_t st) {
+    constexpr int LDS = 4 * 32 * (U2 * 2 + 16);
+    static bool attr_done = false;
+    if (!attr_done) {
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(prenet_chain_kernel<CINP, U1, U2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((prenet_chain_kernel<CINP, U1, U2>), dim3((unsigned)((a.M + 127) / 128)), dim3(256), LDS, st, a);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
 // out[(tile * nks + s) * 64 + lane][e] = W[32 tile + (lane & 31)][kmap(16 s + 8 (lane >> 5) + e)], zero outside W
 __global__ void __launch_bounds__(256)
 mfma_pack_kernel(const __bf16* W, int rows, int K, int ldw, int chained, int ntiles, int nks, __bf16* out) {
@@ -476,6 +587,27 @@ int vc_mfma_pack(const void* d_W, int32_t rows, int32_t K, int32_t ldw, int32_t 
                        static_cast<const __bf16*>(d_W), rows, K, ldw, chained, ntiles, nks, static_cast<__bf16*>(d_packed));
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
+}
+
+int vc_prenet_chain_supported(int32_t cin_padded, int32_t units1, int32_t units2) {
+    return (cin_padded == 64 && units1 == 256 && units2 == 128) || (cin_padded == 80 && units1 == 512 && units2 == 256);
+}
+
+int vc_prenet_chain(const void* d_X, int32_t M, int32_t ldx, int32_t cin_padded, int32_t units1, int32_t units2,
+                    const void* d_pk1, const float* d_b1, const void* d_pk2, const float* d_b2, void* d_Y, int32_t ldy,
+                    void* stream) {
+    VC_REQUIRE(d_X && d_pk1 && d_b1 && d_pk2 && d_b2 && d_Y && M > 0, "vc_prenet_chain: NULL argument or M <= 0");
+    VC_REQUIRE(vc_prenet_chain_supported(cin_padded, units1, units2), "vc_prenet_chain: unsupported shape %d -> %d -> %d", cin_padded, units1, units2);
+    VC_REQUIRE(ldx >= cin_padded && ldx % 8 == 0 && ldy >= units2 && ldy % 8 == 0, "vc_prenet_chain: leading dimensions must be multiples of 8 and cover the rows");
+    VC_REQUIRE(((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_Y) | reinterpret_cast<uintptr_t>(d_pk1) |
+                 reinterpret_cast<uintptr_t>(d_pk2) | reinterpret_cast<uintptr_t>(d_b1) | reinterpret_cast<uintptr_t>(d_b2)) & 15) == 0,
+               "vc_prenet_chain: operands must be 16-byte aligned");
+    PrenetArgs a;
+    a.X = static_cast<const __bf16*>(d_X); a.M = M; a.ldx = ldx;
+    a.pk1 = static_cast<const bf16x8*>(d_pk1); a.pk2 = static_cast<const bf16x8*>(d_pk2);
+    a.b1 = d_b1; a.b2 = d_b2; a.Y = static_cast<__bf16*>(d_Y); a.ldy = ldy;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    return cin_padded == 64 ? launch_prenet_chain<64, 256, 128>(a, st) : launch_prenet_chain<80, 512, 256>(a, st);
 }
 
 int32_t vc_cbhg_front_coef_floats(void) { return CO_TOTAL; }

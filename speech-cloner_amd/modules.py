@@ -451,6 +451,31 @@ def prenet(inputs, num_units=None, embed_size=256, dropout_rate=0.5, is_training
     """modules.py:274-295: dense(E)+relu, dropout, dense(E/2)+relu, dropout."""
     if num_units is None:
         num_units = [embed_size, embed_size // 2]
+    torch = _torch()
+    store = _store()
+    x = _as3(inputs)
+    N_, T_, Cx = x.shape
+    if (not is_training and store.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+            and os.environ.get('VC_PRENET_CHAIN', '1') != '0'
+            and _vc.lib().vc_prenet_chain_supported(Cx, num_units[0], num_units[1])):
+        # both layers in one launch, the intermediate never leaves the registers (vc_prenet_chain)
+        with variable_scope(scope):
+            sc1, sc2 = _scope('dense1'), _scope('dense2')
+            cin = Cx if in_features is None else in_features
+            if sc1 + '/kernel' in store.vars:
+                cin = store.vars[sc1 + '/kernel'].shape[0]
+            if Cx != _pad8(cin):
+                raise ValueError(' - ERROR, prenet {}: input width {} does not match kernel rows {}'.format(sc1, Cx, cin))
+            bt1, b1 = _prep_dense(store, sc1, cin, num_units[0])
+            bt2, b2 = _prep_dense(store, sc2, num_units[0], num_units[1])
+        pk1, pk2 = store.cached(('prenet_pk', sc1), lambda: (_mfma_pack(bt1, num_units[0], Cx, 0),
+                                                               _mfma_pack(bt2, num_units[1], num_units[0], 1)))
+        x = x.contiguous()
+        out = torch.empty((N_, T_, num_units[1]), dtype=store.dtype, device=x.device)
+        _vc.check(_vc.lib().vc_prenet_chain(x.data_ptr(), N_ * T_, Cx, Cx, num_units[0], num_units[1], pk1.data_ptr(),
+                                            b1.data_ptr(), pk2.data_ptr(), b2.data_ptr(), out.data_ptr(), num_units[1],
+                                            _vc.current_stream()))
+        return out
     with variable_scope(scope):
         outputs = dense(inputs, num_units[0], 'relu', name="dense1", in_features=in_features)
         outputs = _dropout(outputs, dropout_rate, is_training)

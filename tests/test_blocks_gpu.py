@@ -377,3 +377,37 @@ def test_encoder_front_single_launch(N, T, L, f32_in, mi, monkeypatch):
     w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
     ref = mo.cbhg(mo.prenet(cast(x.cpu()), w, 'e/prenet'), w, 'e/CBHG', 6, L)
     _close(y, ref, TOL['bfloat16'], 'fused encoder front T=%d L=%d' % (T, L))
+
+
+@pytest.mark.parametrize('N,T,cin,E', [(2, 400, 61, 256), (3, 77, 80, 512), (1, 1, 61, 256), (64, 400, 80, 512)])
+def test_prenet_single_launch(N, T, cin, E, monkeypatch):
+    """The decoder stages' prenet as one launch (vc_prenet_chain: intermediate in registers) against the two
+    dense launches and the oracle; ragged last block, NaN-poisoned LDS."""
+    import modules
+    from conftest import poison_gpu_state
+    rng = np.random.RandomState(cin + E + T)
+    st = _store('bfloat16')
+    cp = modules._pad8(cin)
+    x = np.zeros((N, T, cp), np.float32)
+    x[:, :, :cin] = 0.7 * rng.standard_normal((N, T, cin))
+    xd = modules.convert(torch.from_numpy(x).cuda(), st.dtype)
+    with modules.variable_store(st), modules.variable_scope('p'):
+        monkeypatch.setenv('VC_PRENET_CHAIN', '0')
+        modules.prenet(xd, None, E, 0.1, False, in_features=cin)
+        for n, v in list(st.vars.items()):
+            if n.endswith('bias'):
+                st.assign(n, rng.uniform(-0.3, 0.3, tuple(v.shape)).astype(np.float32))
+        y_ref = modules.prenet(xd, None, E, 0.1, False, in_features=cin)
+        monkeypatch.setenv('VC_PRENET_CHAIN', '1')
+        assert modules._vc.lib().vc_prenet_chain_supported(cp, E, E // 2)
+        poison_gpu_state()
+        y = modules.prenet(xd, None, E, 0.1, False, in_features=cin)
+    torch.cuda.synchronize()
+    assert y.shape == (N, T, E // 2) and not torch.isnan(y.float()).any()
+    d = (y.float() - y_ref.float()).abs()
+    assert d.max().item() < 1e-2, d.max().item()
+    cast = lambda t: t.float().bfloat16().double()
+    w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
+    h = cast(torch.relu(cast(torch.from_numpy(x[:, :, :cin])) @ w['p/prenet/dense1/kernel'] + w['p/prenet/dense1/bias']))
+    ref = torch.relu(h @ w['p/prenet/dense2/kernel'] + w['p/prenet/dense2/bias'])
+    _close(y, ref, TOL['bfloat16'], 'fused prenet %d -> %d' % (cin, E))
