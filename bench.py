@@ -423,8 +423,8 @@ def cpu_baseline_frontend():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--workload', default='full', choices=['full', 'frontend', 'train', 'vocoder'])
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
     ap.add_argument('--window-batch', type=int, default=64)
