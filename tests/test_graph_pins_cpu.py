@@ -266,3 +266,14 @@ def test_loss_metrics_and_learning_rate_schedule(graph):
     sc = tf_bundle.read_bundle(os.path.join(GOLDEN, 'enc_14_ckpt', 'encoder-136512'))
     lr = float(sc['opt/learning_rate_start']) / (1.0 + float(sc['opt/learning_rate_decay']) * float(sc['opt/epoch']))
     assert abs(float(sc['opt/learning_rate']) - lr) < 1e-9
+
+
+def test_fixture_is_the_reference_graph(graph, reference_dir):
+    """Provenance (build container only; skipped where /root/reference is absent): the committed fixture is
+    exactly what tools/make_graph_fixture.py extracts from the reference's .meta file."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('make_graph_fixture', os.path.join(ROOT, 'tools', 'make_graph_fixture.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fresh = json.loads(json.dumps(mod.extract(reference_dir)))
+    assert fresh['nodes'] == graph['nodes'] and fresh['meta_info'] == graph['meta_info']

@@ -154,8 +154,7 @@ def node(b):
     return d
 
 
-def main():
-    ref = sys.argv[1] if len(sys.argv) > 1 else '/root/reference'
+def extract(ref='/root/reference'):
     meta = open(os.path.join(ref, 'enc_14_ckpt', 'encoder-136512.meta'), 'rb').read()
     info, nodes, producer = {}, [], None
     for f, wt, v in fields(meta):
@@ -176,15 +175,15 @@ def main():
     keep = [n for n in nodes if 'gradients' not in n['name'] and 'summar' not in n['name'].lower()
             and not n['name'].startswith('save') and 'Initializer' not in n['name']
             and n['op'] not in ('Assign', 'Fill', 'NoOp', 'ScalarSummary', 'MergeSummary')]
-    out = {'source': 'enc_14_ckpt/encoder-136512.meta', 'meta_info': info, 'graph_producer': producer,
-           'n_nodes_total': len(nodes), 'nodes': keep}
+    return {'source': 'enc_14_ckpt/encoder-136512.meta', 'meta_info': info, 'graph_producer': producer,
+            'n_nodes_total': len(nodes), 'nodes': keep}
+
+
+def main():
+    out = extract(sys.argv[1] if len(sys.argv) > 1 else '/root/reference')
     dst = os.path.join(ROOT, 'tests', 'golden', 'enc_14_graph.json')
     json.dump(out, open(dst, 'w'), separators=(',', ':'), sort_keys=True)
-    print('%d nodes total, %d kept -> %s (%d bytes)' % (len(nodes), len(keep), dst, os.path.getsize(dst)))
-    ops = {}
-    for n in keep:
-        ops[n['op']] = ops.get(n['op'], 0) + 1
-    print(sorted(ops.items(), key=lambda kv: -kv[1])[:40])
+    print('%d nodes total, %d kept -> %s (%d bytes)' % (out['n_nodes_total'], len(out['nodes']), dst, os.path.getsize(dst)))
 
 
 if __name__ == '__main__':
