@@ -36,7 +36,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-BN_EPS = 1e-3
+BN_EPS = float(np.float32(1e-3))          # FusedBatchNorm's epsilon attribute as the saved graph holds it (float32)
 BN_DECAY = 0.999
 
 
@@ -56,7 +56,7 @@ def dropout(x, rate, mask=None):
     mask is None (inference)."""
     if mask is None:
         return x
-    keep = 1.0 - rate
+    keep = float(np.float32(1.0 - rate))     # the saved graph holds keep_prob as a float32 constant (0.6 -> 0.60000002)
     return x / keep * mask
 
 
@@ -92,10 +92,9 @@ def bn(x, w, scope, is_training=False, stats_out=None):
         var = ((x - mean) ** 2).mean(dim=red)                   # biased
         if stats_out is not None:
             unb = var * (n / max(n - 1, 1))
-            stats_out[scope + '/moving_mean'] = (
-                w[scope + '/moving_mean'] * BN_DECAY + mean.detach() * (1 - BN_DECAY))
-            stats_out[scope + '/moving_variance'] = (
-                w[scope + '/moving_variance'] * BN_DECAY + unb.detach() * (1 - BN_DECAY))
+            d = float(np.float32(1.0 - BN_DECAY))        # AssignMovingAvg: moving -= (moving - batch) * decay (float32 constant)
+            stats_out[scope + '/moving_mean'] = w[scope + '/moving_mean'] - (w[scope + '/moving_mean'] - mean.detach()) * d
+            stats_out[scope + '/moving_variance'] = w[scope + '/moving_variance'] - (w[scope + '/moving_variance'] - unb.detach()) * d
     else:
         mean, var = w[scope + '/moving_mean'], w[scope + '/moving_variance']
     return (x - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta

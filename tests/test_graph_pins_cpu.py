@@ -115,7 +115,7 @@ def test_convolutions_norms_and_pooling(graph):
     norms = _ops(graph, 'FusedBatchNorm')
     assert len(norms) == 3
     for n in norms:
-        assert n['attr']['epsilon'] == float(np.float32(mo.BN_EPS)) and n['attr']['data_format'] == 'NHWC'
+        assert n['attr']['epsilon'] == mo.BN_EPS == float(np.float32(1e-3)) and n['attr']['data_format'] == 'NHWC'
     decays = [n for n in graph['nodes'] if n['op'] == 'Const' and n['name'].endswith('/decay') and 'AssignMovingAvg' in n['name']]
     assert len(decays) == 6
     for n in decays:                                                     # moving -= (moving - batch) * (1 - 0.999)
@@ -133,7 +133,7 @@ def test_convolutions_norms_and_pooling(graph):
     ref = torch.stack([sum(xp[:, t + j] @ w[j] for j in range(k)) for t in range(7)], 1)
     assert torch.allclose(mo.conv1d(x[:, :, :cin], w), ref, atol=1e-12)
     import modules
-    assert (modules.BN_EPS, modules.BN_DECAY) == (mo.BN_EPS, mo.BN_DECAY)   # the product's constants too
+    assert (float(np.float32(modules.BN_EPS)), modules.BN_DECAY) == (mo.BN_EPS, mo.BN_DECAY)   # the product's constants too (passed as float32)
 
 
 def test_projections_are_wired_as_the_oracle_reads_them(graph):
@@ -277,3 +277,124 @@ def test_fixture_is_the_reference_graph(graph, reference_dir):
     spec.loader.exec_module(mod)
     fresh = json.loads(json.dumps(mod.extract(reference_dir)))
     assert fresh['nodes'] == graph['nodes'] and fresh['meta_info'] == graph['meta_info']
+
+
+# ------------------------------------------------------------------------------------------------------
+# The WHOLE forward graph, as the reference saved it (training mode: dropout, batch statistics), evaluated
+# on the reference's trained weights and compared with the oracle's forward.  What the interpreter below
+# supplies itself are TensorFlow's primitive kernels ([ext] in SURVEY.md: SAME convolution / pooling
+# arithmetic, FusedBatchNorm on batch statistics, Tensordot = matmul over the last axis, softmax); every
+# connection between them -- which tensor feeds which layer, dropout placement, concat orders, the residual,
+# time reversal of the backward recurrence, the loop-carried state -- is read from the saved graph.
+class _FullInterp(_Interp):
+    def __init__(self, graph, feeds, weights):
+        super().__init__(graph, feeds)
+        self.w = weights
+
+    def const(self, name):
+        v = self.N[name]['attr']['value']
+        return v['value'] if 'value' in v else None
+
+    def node(self, name):
+        if name in self.memo:
+            return self.memo[name]
+        n = self.N[name]
+        op, ins = n['op'], [i for i in n['input'] if not i.startswith('^')]
+        out = None
+        if op == 'VariableV2':
+            out = self.w[name]
+        elif op == 'Reshape' and name.endswith('/Tensordot'):
+            # tf.layers.dense on [B, T, C]: tensordot(x, kernel, [[2], [0]]) lowered to transpose/reshape/MatMul/reshape
+            scope = name
+            assert self.const(scope + '/axes') == [2]
+            x = self.get(self.N[scope + '/transpose']['input'][0])
+            k = self.get(self.N[scope + '/transpose_1']['input'][0])
+            mm = self.N[scope + '/MatMul']
+            assert not mm['attr']['transpose_a'] and not mm['attr']['transpose_b']
+            out = x @ k
+        elif op == 'ExpandDims':
+            out = self.get(ins[0]).unsqueeze(int(self.const(ins[1])[0]))
+        elif op == 'Squeeze':
+            out = self.get(ins[0]).squeeze(n['attr']['squeeze_dims'][0])
+        elif op == 'Conv2D':                             # [B, 1, T, C] * [1, k, C, O], NHWC, stride 1, SAME
+            a = n['attr']
+            assert (a['padding'], a['data_format'], a['strides']) == ('SAME', 'NHWC', [1, 1, 1, 1])
+            x, k = self.get(ins[0]), self.get(ins[1])
+            assert x.shape[1] == 1 and k.shape[0] == 1
+            out = mo.conv1d(x[:, 0], k[0]).unsqueeze(1)
+        elif op == 'FusedBatchNorm':                     # training mode: batch statistics over (B, H, W)
+            assert n['attr']['is_training'] is True
+            x, g_, b_ = self.get(ins[0]), self.get(ins[1]), self.get(ins[2])
+            mean = x.mean(dim=(0, 1, 2))
+            var = ((x - mean) ** 2).mean(dim=(0, 1, 2))
+            cnt = x.numel() // x.shape[-1]                # outputs 1, 2: batch mean, UNBIASED batch variance ([ext])
+            out = [(x - mean) * torch.rsqrt(var + n['attr']['epsilon']) * g_ + b_, mean, var * (cnt / (cnt - 1.0))]
+        elif op == 'MaxPool':
+            assert (n['attr']['ksize'], n['attr']['strides'], n['attr']['padding']) == ([1, 1, 2, 1], [1, 1, 1, 1], 'SAME')
+            x = self.get(ins[0])
+            out = torch.maximum(x, torch.cat([x[:, :, 1:], x[:, :, -1:]], 2))
+        elif op == 'ReverseV2':
+            out = torch.flip(self.get(ins[0]), dims=[int(v) for v in self.const(ins[1])])
+        elif op == 'Transpose':                          # dynamic_rnn: batch-major <-> time-major
+            out = self.get(ins[0]).transpose(0, 1)
+        elif op == 'TensorArrayGatherV3':                # the while loop: iterate the saved cell sub-graph
+            base = name[:name.index('/TensorArrayStack')]            # .../bidirectional_rnn/fw/fw
+            loop = base + '/while/'
+            seq = self.get(base + '/transpose')                      # [T, B, C], what the loop's TensorArray was filled with
+            scat = self.N[base + '/TensorArrayUnstack/TensorArrayScatter/TensorArrayScatterV3']
+            assert scat['input'][2] == base + '/transpose'
+            cell = base.rsplit('/', 1)[0] + '/gru_cell'               # variables live under .../fw/gru_cell
+            h = torch.zeros(seq.shape[1], self.w[cell + '/candidate/bias'].shape[0], dtype=seq.dtype)
+            outs = []
+            for t in range(seq.shape[0]):
+                feeds = {loop + 'TensorArrayReadV3': seq[t], loop + 'Identity_3': h}
+                for v in ('gates/kernel', 'gates/bias', 'candidate/kernel', 'candidate/bias'):
+                    feeds[cell + '/' + v + '/read'] = self.w[cell + '/' + v]
+                h = _Interp({'by_name': self.N}, feeds).get(loop + 'gru_cell/add')
+                outs.append(h)
+            out = torch.stack(outs, 0)
+        elif op == 'Softmax':
+            out = torch.softmax(self.get(ins[0]), -1)
+        elif op == 'Reshape' and name == 'encoder/Reshape':
+            x = self.get(ins[0]); out = x.reshape(-1, x.shape[-1])
+        elif op == 'Reshape' and name == 'encoder/y_pred':
+            out = self.get(ins[0]).reshape(self.get('encoder/y_logits/BiasAdd').shape)
+        if out is None:
+            return super().node(name)
+        self.memo[name] = out
+        return out
+
+
+def test_whole_forward_graph_on_the_trained_weights(graph):
+    import tf_bundle
+    cfg = json.load(open(os.path.join(ROOT, 'speech-cloner_amd', 'hp', 'encoder_cfg_d.json')))
+    w = mo.to_torch({k: v for k, v in tf_bundle.read_bundle(os.path.join(GOLDEN, 'enc_14_ckpt', 'encoder-136512')).items()
+                     if k.startswith('encoder/')}, torch.float64)
+    g = np.load(os.path.join(GOLDEN, 'encoder_fwd.npz'))
+    x = torch.from_numpy(g['x'][:2, :96]).double()                  # 2 windows x 96 frames of real front-end features
+    rng = np.random.RandomState(6)
+    m1 = torch.from_numpy((rng.rand(2, 96, 80) < 0.6).astype(np.float64))
+    m2 = torch.from_numpy((rng.rand(2, 96, 40) < 0.6).astype(np.float64))
+    it = _FullInterp(graph, {'encoder/inputs': x, 'encoder/prenet/dropout1/dropout/Floor': m1,
+                             'encoder/prenet/dropout2/dropout/Floor': m2}, w)
+    logits_g = it.get('encoder/y_logits/BiasAdd')
+    pred_g = it.get('encoder/y_pred')
+    taps = {}
+    stats = {}
+    logits, pred, cls, out = mo.encoder_forward(x, w, cfg, taps=taps, is_training=True, masks=(m1, m2), stats_out=stats)
+    # moving statistics after the step (updates_collections=None: AssignSub of (moving - batch) * decay)
+    for var_scope, op_scope in (('encoder/CBHG/conv1d_banks/bn', 'encoder/CBHG/conv1d_banks/bn'),
+                                ('encoder/CBHG/conv1d_1', 'encoder/CBHG/conv1d_1_1'), ('encoder/CBHG/conv1d_2', 'encoder/CBHG/conv1d_2_1')):
+        for stat, upd in (('moving_mean', 'AssignMovingAvg'), ('moving_variance', 'AssignMovingAvg_1')):
+            asg = graph['by_name']['%s/%s' % (op_scope, upd)]
+            assert asg['op'] == 'AssignSub' and asg['input'][0] == '%s/%s' % (var_scope, stat)
+            new = w['%s/%s' % (var_scope, stat)] - it.get(asg['input'][1])
+            assert torch.allclose(new, stats['%s/%s' % (var_scope, stat)], atol=1e-12), (var_scope, stat)
+    assert torch.allclose(it.get('encoder/prenet/dropout2/dropout/mul'), taps['prenet'], atol=1e-12)
+    assert torch.allclose(it.get('encoder/CBHG/highwaynet_0/add'), taps['highway'], atol=1e-10)
+    assert torch.allclose(it.get('encoder/CBHG/gru/concat'), out, atol=1e-10)
+    assert torch.allclose(logits_g, logits, atol=1e-9) and torch.allclose(pred_g, pred, atol=1e-10)
+    assert torch.equal(logits_g.argmax(-1).to(torch.int32), cls)
+    # the interpreter really walked the graph: every layer type was visited
+    assert {'Conv2D', 'FusedBatchNorm', 'MaxPool', 'ReverseV2', 'TensorArrayGatherV3', 'Softmax'} <= {
+        graph['by_name'][k]['op'] for k in it.memo if k in graph['by_name']}
