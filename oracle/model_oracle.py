@@ -22,10 +22,16 @@ its published op semantics are restated:
   * bidirectional_dynamic_rnn: zero initial state, backward = reverse-run-reverse, concat,
   * tf.layers.dropout: x / keep * floor(keep + U[0,1)) in training, identity otherwise.
 
-PARITY STATUS: **parity unpinned** against TensorFlow itself (the reference has no tests or
-golden activations).  Pinned inputs: the real trained weights of enc_14_ckpt (per-tensor
-CRC32C verified by the bundle reader) and the variable names/shapes listed in SURVEY.md
-section 8c.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+PARITY STATUS: **parity unpinned** against TensorFlow's own kernels (the reference has no tests or
+golden activations, TensorFlow cannot run here).  Pinned by the reference's artefacts: the real
+trained weights of enc_14_ckpt (per-tensor CRC32C verified by the bundle reader), the variable
+names/shapes of SURVEY.md section 8c, and the graph the reference's Saver wrote next to those weights
+(enc_14_ckpt/encoder-136512.meta -> tests/golden/enc_14_graph.json): tests/test_graph_pins_cpu.py
+checks every attribute used here against it and evaluates the saved forward graph (GRU cell and
+highway block node by node; the whole training-mode forward on the trained weights) with a small
+interpreter -- this module returns the same numbers to 1e-10.  Only the primitive kernels the
+interpreter has to supply (SAME padding arithmetic, FusedBatchNorm's variances) remain a reading of
+TensorFlow's documentation.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
 this module.
 
 Weights are a dict  TF variable name -> torch tensor  in TF layout.
