@@ -1,0 +1,48 @@
+"""A/B of run-time switches INSIDE the three-stream step, on one box, interleaved (ABAB...) so that box and
+clock drift cancel: every configuration runs `rounds` times `steps` steps; mean and spread of ms/step.
+  python tools/ab_step.py "VC_PRENET_CHAIN=0" "VC_BANK256_XCD=1" ...      (the default is always included)"""
+import os, sys, time, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'speech-cloner_amd')):
+    sys.path.insert(0, p)
+import torch, bench, audio_lib
+cfgs = [''] + sys.argv[1:]
+keys = sorted({kv.split('=')[0] for c in cfgs for kv in c.split(',') if kv})
+NS, steps, rounds = 3, 40, 6
+wav = bench.synth_audio(32, 64000, seed=0).cuda()
+enc, dec = bench.load_models('bfloat16', 0)
+streams = [torch.cuda.Stream() for _ in range(NS)]
+fe_out, cnt = None, [0]
+def step():
+    global fe_out
+    fe_out = audio_lib.calc_MFCC_input_batch(wav, None, out=fe_out, **bench.FE_KW)
+    x = fe_out[0][:, :800, :].reshape(64, 400, 80)
+    main = torch.cuda.current_stream()
+    ready = torch.cuda.Event(); ready.record(main)
+    st_ = streams[cnt[0] % NS]; cnt[0] += 1
+    st_.wait_event(ready)
+    with torch.cuda.stream(st_):
+        xi = x.contiguous(); xi.record_stream(st_)
+        ev = torch.cuda.Event(); ev.record(st_); main.wait_event(ev)
+        dec.forward(xi)
+def apply(c):
+    for k in keys: os.environ.pop(k, None)
+    for kv in c.split(','):
+        if kv: k, v = kv.split('='); os.environ[k] = v
+res = {c: [] for c in cfgs}
+for c in cfgs:                                   # build every cache first
+    apply(c)
+    for _ in range(4): step()
+torch.cuda.synchronize()
+for r in range(rounds):
+    for c in cfgs:
+        apply(c)
+        for _ in range(6): step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps): step()
+        torch.cuda.synchronize()
+        res[c].append((time.perf_counter() - t0) / steps * 1e3)
+base = statistics.mean(res[''])
+for c in cfgs:
+    v = res[c]
+    print('%-28s %.4f ms/step  (min %.4f max %.4f)  %+5.2f %% vs default' % (c or 'default', statistics.mean(v), min(v), max(v), 100 * (statistics.mean(v) / base - 1)))
