@@ -7,6 +7,11 @@ import ctypes as C
 import os
 import threading
 
+# Work that is independent (window chunks in decoder.predict(n_streams=...), consecutive batches) is pipelined over
+# HIP streams; the runtime folds streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams sharing a
+# queue serialise.  Takes effect only if set before the HIP runtime initialises (the first GPU call of the process).
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VC_LIB_PATH', os.path.join(_HERE, 'libvc_hip.so'))   # override: kernel A/B experiments
 

@@ -11,7 +11,8 @@ keys = sorted({kv.split('=')[0] for c in cfgs for kv in c.split(',') if kv})
 NS, steps, rounds = 3, 40, 6
 wav = bench.synth_audio(32, 64000, seed=0).cuda()
 enc, dec = bench.load_models('bfloat16', 0)
-streams = [torch.cuda.Stream() for _ in range(NS)]
+streams = [torch.cuda.Stream() for _ in range(16)]
+ns = [NS]
 fe_out, cnt = None, [0]
 def step():
     global fe_out
@@ -19,7 +20,7 @@ def step():
     x = fe_out[0][:, :800, :].reshape(64, 400, 80)
     main = torch.cuda.current_stream()
     ready = torch.cuda.Event(); ready.record(main)
-    st_ = streams[cnt[0] % NS]; cnt[0] += 1
+    st_ = streams[cnt[0] % ns[0]]; cnt[0] += 1
     st_.wait_event(ready)
     with torch.cuda.stream(st_):
         xi = x.contiguous(); xi.record_stream(st_)
@@ -27,8 +28,12 @@ def step():
         dec.forward(xi)
 def apply(c):
     for k in keys: os.environ.pop(k, None)
+    ns[0] = NS
     for kv in c.split(','):
-        if kv: k, v = kv.split('='); os.environ[k] = v
+        if kv:
+            k, v = kv.split('=')
+            if k == 'STREAMS': ns[0] = int(v)              # pseudo-switch: number of streams the steps rotate over
+            else: os.environ[k] = v
 res = {c: [] for c in cfgs}
 for c in cfgs:                                   # build every cache first
     apply(c)
