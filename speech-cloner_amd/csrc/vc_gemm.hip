@@ -856,7 +856,9 @@ bool conv256_ok(const vc_gemm_desc* d) {
     const char* e = std::getenv("VC_CONV256");           // VC_CONV256=0: A/B switch back to conv_kernel / gemm_kernel
     if ((e && e[0] == '0') || d->dtype != VC_BF16 || d->mode != VC_GEMM_PLAIN || d->n_groups != 1) return false;
     const vc_gemm_group& g = d->groups[0];
-    if (d->N % 128 || d->Cin % 64 || d->M < 128 || g.taps > 7 || g.taps * d->Cin < 1024) return false;
+    const char* mk = std::getenv("VC_CONV256_MINK");     // shortest K that takes this kernel (A/B)
+    const int min_k = mk ? std::atoi(mk) : 384;           // measured in the pipelined step: 1024 -> 384 = -0.9 % ms/step (the second k = 3 projections)
+    if (d->N % 128 || d->Cin % 64 || d->M < 128 || g.taps > 7 || g.taps * d->Cin < min_k) return false;
     if (d->d_pro_scale || d->pro_relu || d->pro_pool == 1 || d->out_f32 || d->drop_keep > 0.0f) return false;
     if ((reinterpret_cast<uintptr_t>(d->d_C) & 15) || d->ldx % 8 || d->ldc % 8 || g.c_off % 8) return false;
     if (d->d_R && ((reinterpret_cast<uintptr_t>(d->d_R) & 7) || d->ldr % 4)) return false;

@@ -8,7 +8,7 @@ for p in (ROOT, os.path.join(ROOT, 'speech-cloner_amd')):
 import torch, bench, audio_lib
 cfgs = [''] + sys.argv[1:]
 keys = sorted({kv.split('=')[0] for c in cfgs for kv in c.split(',') if kv})
-NS, steps, rounds = 3, 40, 6
+NS, steps, rounds = 10, 60, 6
 wav = bench.synth_audio(32, 64000, seed=0).cuda()
 enc, dec = bench.load_models('bfloat16', 0)
 streams = [torch.cuda.Stream() for _ in range(16)]
