@@ -7,6 +7,7 @@ struct Bank256Pair {
     const void* Bt0;      // narrower filter: [128][taps0 * Cin] bf16, K contiguous
     const void* Bt1;      // wider filter:    [128][(taps0 + 1) * Cin]
     int32_t taps0, pad_l, c_off0, c_off1;
+    int32_t extra;        // taps of the second filter - taps0: 1 for a bank pair, 0 for the two halves of ONE 256-channel filter
 };
 
 struct Bank256Args {

@@ -74,7 +74,7 @@ bank256_kernel(Bank256Args a) {
     }
     const Bank256Pair pr = a.p[psel];
     const int m0 = rt * (a.pool ? BM - 1 : BM);            // pooled output: tiles overlap by one frame
-    const int ntap = pr.taps0 + 1;                     // taps of the wider filter
+    const int ntap = pr.taps0 + pr.extra;              // taps of the wider filter
     const int nslab = a.Cin >> 6;
     const int ntiles = nslab * ntap;
     const int pad_l = pr.pad_l;

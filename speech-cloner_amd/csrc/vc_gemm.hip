@@ -840,6 +840,7 @@ int launch_bank256(const vc_gemm_desc* d, hipStream_t st) {
         p.Bt0 = d->groups[g].d_Bt; p.Bt1 = d->groups[g + 1].d_Bt;
         p.taps0 = d->groups[g].taps; p.pad_l = d->groups[g].pad_l;
         p.c_off0 = d->groups[g].c_off; p.c_off1 = d->groups[g + 1].c_off;
+        p.extra = 1;
     }
     b.dbg = 0;
     if (const char* dbg = std::getenv("VC_BANK256_DBG")) b.dbg = std::atoi(dbg);
@@ -865,6 +866,36 @@ bool conv256_ok(const vc_gemm_desc* d) {
     return true;
 }
 
+// A single 256-channel filter with a long K (the first k = 3 projection of decoder stage 2: K = 3 x 4096) on the
+// bank kernel's 256 x 256 tiles, its two 128-channel halves standing in for a pair of equal width: 0.75 fragment
+// reads per MFMA instead of conv256_kernel's 1.0 and half the weight traffic per frame.  Only M / 256 workgroups
+// (100 at 64 windows), so ALONE on the chip the launch is slower than conv256_kernel's 200 (0.29 vs 0.23 ms) -- but
+// CU time, not the makespan, is what a launch costs once several batches are in flight:
+// 100 x 0.29 ms against 200 x 0.23 ms.  VC_PROJ256=0 switches it off.
+bool proj256_ok(const vc_gemm_desc* d) {
+    const char* e = std::getenv("VC_PROJ256");
+    if ((e && e[0] == '0') || d->dtype != VC_BF16 || d->mode != VC_GEMM_PLAIN || d->n_groups != 1) return false;
+    const vc_gemm_group& g = d->groups[0];
+    if (d->N != 256 || d->Cin % 64 || d->M < 1024 || g.taps < 1 || g.taps > 32 || g.taps * d->Cin < 4096) return false;
+    if (d->d_pro_scale || d->pro_relu || d->pro_pool || d->d_R || d->out_f32 || d->drop_keep > 0.0f || d->epi_pool) return false;
+    if (d->act != VC_ACT_NONE && d->act != VC_ACT_RELU) return false;
+    if ((reinterpret_cast<uintptr_t>(d->d_C) & 15) || d->ldx % 8 || d->ldc % 8 || g.c_off % 8) return false;
+    return true;
+}
+
+int launch_proj256(const vc_gemm_desc* d, hipStream_t st) {
+    Bank256Args b;
+    const vc_gemm_group& g = d->groups[0];
+    b.X = d->d_X; b.M = d->M; b.T = d->T; b.Cin = d->Cin; b.ldx = d->ldx;
+    b.epi_scale = d->d_epi_scale; b.epi_shift = d->d_epi_shift; b.act = d->act;
+    b.C = d->d_C; b.ldc = d->ldc; b.n_pairs = 1; b.pool = 0; b.dbg = 0;
+    Bank256Pair& p = b.p[0];
+    p.Bt0 = g.d_Bt;
+    p.Bt1 = static_cast<const char*>(g.d_Bt) + (size_t)128 * g.K * 2;      // rows 128.. of the [256, K] bf16 matrix
+    p.taps0 = g.taps; p.pad_l = g.pad_l; p.c_off0 = g.c_off; p.c_off1 = g.c_off + 128; p.extra = 0;
+    return vc_launch_bank256(b, st);
+}
+
 int launch_conv256(const vc_gemm_desc* d, hipStream_t st) {
     Conv256Args c;
     const vc_gemm_group& g = d->groups[0];
@@ -877,6 +908,7 @@ int launch_conv256(const vc_gemm_desc* d, hipStream_t st) {
 }
 
 template <typename T> int launch(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
+    if (sizeof(T) == 2 && proj256_ok(d)) return launch_proj256(d, st);
     if (sizeof(T) == 2 && conv256_ok(d)) return launch_conv256(d, st);
     // convolution-specialised kernel: every group has taps in [2, 32] (a grouped bank launch may
     // include its k = 1 member) and Cin is a whole number of channel slabs

@@ -411,3 +411,32 @@ def test_prenet_single_launch(N, T, cin, E, monkeypatch):
     h = cast(torch.relu(cast(torch.from_numpy(x[:, :, :cin])) @ w['p/prenet/dense1/kernel'] + w['p/prenet/dense1/bias']))
     ref = torch.relu(h @ w['p/prenet/dense2/kernel'] + w['p/prenet/dense2/bias'])
     _close(y, ref, TOL['bfloat16'], 'fused prenet %d -> %d' % (cin, E))
+
+
+@pytest.mark.parametrize('N,T,cin,k', [(4, 400, 4096, 3), (5, 250, 1024, 5), (3, 400, 2048, 2)])
+def test_wide_projection_on_the_bank_tiles(N, T, cin, k, monkeypatch):
+    """A single 256-channel convolution with a long K (decoder stage 2's first k = 3 projection) runs on the bank
+    kernel's 256 x 256 tiles (its halves as a pair of EQUAL width): bit-identical to conv256_kernel / conv_kernel,
+    window edges and a ragged last tile included, NaN-poisoned LDS."""
+    import modules
+    from conftest import poison_gpu_state
+    rng = np.random.RandomState(cin + k)
+    st = _store('bfloat16')
+    x = torch.from_numpy(rng.standard_normal((N, T, cin)).astype(np.float32) * 0.5)
+    xd = modules.convert(x.cuda(), st.dtype)
+    with modules.variable_store(st), modules.variable_scope('p'):
+        monkeypatch.setenv('VC_PROJ256', '0')
+        kw = dict(filters=256, size=k, scope='c', bn_scope='c', activation_fn='relu')
+        modules.conv1d(xd, **kw)
+        for n, v in list(st.vars.items()):
+            if n.endswith('gamma') or n.endswith('moving_variance'):
+                st.assign(n, rng.uniform(0.5, 1.5, tuple(v.shape)).astype(np.float32))
+            elif n.endswith('beta') or n.endswith('moving_mean'):
+                st.assign(n, rng.uniform(-0.3, 0.3, tuple(v.shape)).astype(np.float32))
+        y_ref = modules.conv1d(xd, **kw)
+        monkeypatch.setenv('VC_PROJ256', '1')
+        poison_gpu_state()
+        y = modules.conv1d(xd, **kw)
+    torch.cuda.synchronize()
+    assert not torch.isnan(y.float()).any()
+    assert torch.equal(y, y_ref)
