@@ -214,7 +214,7 @@ class decoder_specs:
         import torch
         n_chunks = (x.shape[0] + batch_size - 1) // batch_size
         use_streams = n_streams > 1 and n_chunks > 1 and torch.cuda.is_available()
-        if use_streams and getattr(self, '_streams', None) is None:
+        if use_streams and len(getattr(self, '_streams', None) or ()) != n_streams:
             self._streams = [torch.cuda.Stream() for _ in range(n_streams)]
         outs = []
         main = torch.cuda.current_stream() if torch.cuda.is_available() else None
