@@ -43,3 +43,30 @@ def test_version_and_errors_without_gpu():
 def test_struct_layout_matches_header():
     import _vc
     assert ctypes.sizeof(_vc.FrontendCfg) == 14 * 4
+
+
+def test_fused_launch_shape_queries_and_validation_without_gpu():
+    """The shape predicates of the fused launches are pure host code, and argument validation of the fused entry
+    points fails (loudly, with a message) before any HIP call."""
+    import _vc
+    lib = _vc.lib()
+    # the shipped encoder shape (hp/encoder_cfg_d.json) takes the one-launch front; nothing else does
+    assert lib.vc_cbhg_front_supported(80, 80, 40, 6, 128, 1, 40, 400) == 1
+    for bad in ((80, 80, 40, 16, 128, 1, 40, 400), (61, 256, 128, 32, 128, 4, 128, 400), (80, 80, 40, 6, 128, 5, 40, 400),
+                (80, 80, 40, 6, 128, 1, 40, 4)):
+        assert lib.vc_cbhg_front_supported(*bad) == 0, bad
+    assert lib.vc_cbhg_front_coef_floats() == 3232                  # layout documented in include/vc_hip.h
+    assert lib.vc_prenet_chain_supported(64, 256, 128) == 1 and lib.vc_prenet_chain_supported(80, 512, 256) == 1
+    assert lib.vc_prenet_chain_supported(80, 80, 40) == 0 and lib.vc_prenet_chain_supported(64, 512, 256) == 0
+    d = _vc.CbhgFrontDesc()
+    d.n_features, d.prenet_units, d.width, d.n_banks, d.bank_filters, d.n_highway, d.gru_units, d.T = 80, 80, 40, 6, 128, 1, 40, 400
+    rc = lib.vc_cbhg_front(ctypes.byref(d), None)                    # every pointer NULL
+    assert rc != 0 and b'vc_cbhg_front' in lib.vc_last_error()
+    d.n_banks = 16
+    rc = lib.vc_cbhg_front(ctypes.byref(d), None)
+    assert rc != 0 and b'unsupported shape' in lib.vc_last_error()
+    rc = lib.vc_prenet_chain(None, 128, 80, 80, 512, 256, None, None, None, None, None, 256, None)
+    assert rc != 0 and b'vc_prenet_chain' in lib.vc_last_error()
+    rc = lib.vc_mfma_pack(None, 32, 16, 16, 0, None, None)
+    assert rc != 0 and b'vc_mfma_pack' in lib.vc_last_error()
+    assert ctypes.sizeof(_vc.CbhgFrontDesc) % 8 == 0
