@@ -13,6 +13,7 @@ wav = bench.synth_audio(32, 64000, seed=0).cuda()
 enc, dec = bench.load_models('bfloat16', 0)
 streams = [torch.cuda.Stream() for _ in range(16)]
 ns = [NS]
+chunk = [64]
 fe_out, cnt = None, [0]
 def step():
     global fe_out
@@ -20,19 +21,21 @@ def step():
     x = fe_out[0][:, :800, :].reshape(64, 400, 80)
     main = torch.cuda.current_stream()
     ready = torch.cuda.Event(); ready.record(main)
-    st_ = streams[cnt[0] % ns[0]]; cnt[0] += 1
-    st_.wait_event(ready)
-    with torch.cuda.stream(st_):
-        xi = x.contiguous(); xi.record_stream(st_)
-        ev = torch.cuda.Event(); ev.record(st_); main.wait_event(ev)
-        dec.forward(xi)
+    for i in range(0, 64, chunk[0]):
+        st_ = streams[cnt[0] % ns[0]]; cnt[0] += 1
+        st_.wait_event(ready)
+        with torch.cuda.stream(st_):
+            xi = x[i:i + chunk[0]].contiguous(); xi.record_stream(st_)
+            ev = torch.cuda.Event(); ev.record(st_); main.wait_event(ev)
+            dec.forward(xi)
 def apply(c):
     for k in keys: os.environ.pop(k, None)
-    ns[0] = NS
+    ns[0] = NS; chunk[0] = 64
     for kv in c.split(','):
         if kv:
             k, v = kv.split('=')
             if k == 'STREAMS': ns[0] = int(v)              # pseudo-switch: number of streams the steps rotate over
+            elif k == 'CHUNK': chunk[0] = int(v)           # pseudo-switch: windows per launch (64 = one chunk per step)
             else: os.environ[k] = v
 res = {c: [] for c in cfgs}
 for c in cfgs:                                   # build every cache first
