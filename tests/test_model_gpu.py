@@ -156,3 +156,31 @@ def test_predict_stream_overlap_is_bit_identical(golden_dir):
         for u_, v_ in zip(a, b):
             assert not np.isnan(v_).any()
             assert np.array_equal(u_, v_)
+
+
+def test_full_batches_in_flight_are_bit_identical(golden_dir):
+    """The bench's configuration: 64-window batches (MFMA recurrences, paired bank tiles, the projection on bank
+    tiles, the fused encoder front and prenets) issued on several HIP streams at once must give exactly the
+    sequential results; eight streams over single-window chunks likewise (the small-batch kernels)."""
+    from encoder import encoder_spec_phn
+    from decoder import decoder_specs
+    from conftest import poison_gpu_state
+    g = np.load(os.path.join(golden_dir, 'encoder_fwd.npz'))
+    dec_cfg = json.load(open(os.path.join(HP, 'decoder_cfg_d.json')))
+    dec_cfg['is_training'] = False
+    enc = encoder_spec_phn(_enc_cfg(golden_dir, 'bfloat16'), None)
+    dec = decoder_specs(dec_cfg, None, enc)
+    rng = np.random.RandomState(9)
+    big = np.concatenate([g['x'] * s for s in rng.uniform(0.2, 1.0, 86)], 0)[:256]      # 256 windows = 4 batches of 64
+    a = dec.predict(big, batch_size=64, n_streams=1)
+    for n_streams in (4, 2):
+        poison_gpu_state()
+        b = dec.predict(big, batch_size=64, n_streams=n_streams)
+        for u_, v_ in zip(a, b):
+            assert not np.isnan(v_).any() and np.array_equal(u_, v_)
+    small = big[:17]
+    a = dec.predict(small, batch_size=1, n_streams=1)
+    poison_gpu_state()
+    b = dec.predict(small, batch_size=1, n_streams=8)
+    for u_, v_ in zip(a, b):
+        assert np.array_equal(u_, v_)
