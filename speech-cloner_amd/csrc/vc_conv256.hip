@@ -17,6 +17,7 @@
 //   * residual add and any activation in the epilogue.
 #include "vc_common.h"
 #include "vc_conv256.h"
+#include <cstdlib>
 
 namespace {
 
@@ -25,9 +26,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
-constexpr int BM = 128;
-constexpr int A_ROWS = 136;                        // 17 row blocks of 8: 128 + (taps - 1 <= 6) + 1 pool row
-constexpr int A_BYTES = A_ROWS * 128;
+// rows per block = 64 * WM (WM row groups of waves); the activation slab holds 8 more rows: taps - 1 <= 6 and 1 pool row
+constexpr int a_rows(int wm) { return 64 * wm + 8; }
 
 __device__ __forceinline__ void glds16(const void* g, void* l) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(uintptr_t)g,
@@ -50,17 +50,22 @@ __device__ __forceinline__ float act_fn(float v, int act) {
 // counted wait: everything but the newest `n` LDS-direct loads of this wave has landed
 __device__ __forceinline__ void wait_loads_but(int n) {
     if (n >= 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if (n >= 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
     else if (n >= 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+    else if (n >= 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 }
 
-template <int WN, bool POOL, int NBUF>
-__global__ void __launch_bounds__(128 * WN, 1)
+template <int WN, bool POOL, int NBUF, int WM>
+__global__ void __launch_bounds__(64 * WM * WN, 1)
 conv256_kernel(Conv256Args a) {
-    constexpr int BN = 64 * WN, NWAVE = 2 * WN, NTHR = 128 * WN;
+    constexpr int BM = 64 * WM, A_ROWS = a_rows(WM), A_BYTES = A_ROWS * 128;
+    constexpr int BN = 64 * WN, NWAVE = WM * WN, NTHR = 64 * NWAVE;
+    constexpr int BQ = (BN / 8) / NWAVE;               // weight-tile loads per wave: 4 (two row groups) or 2 (four)
+    static_assert(BQ * NWAVE * 8 == BN && (BQ == 2 || BQ == 4), "weight tile split");
     constexpr int DIST = NBUF - 1;                     // weight tiles in flight ahead of the one being read
     constexpr int B_BYTES = BN * 128;
-    constexpr int AQ = (A_ROWS / 8 + NWAVE - 1) / NWAVE;        // staging passes over the 17 row blocks
+    constexpr int AQ = (A_ROWS / 8 + NWAVE - 1) / NWAVE;        // staging passes over the slab's row blocks
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const As = smem;                             // [2][136][128]
     char* const Bs = smem + 2 * A_BYTES;               // [NBUF][BN][128]
@@ -83,9 +88,9 @@ conv256_kernel(Conv256Args a) {
         a_src[q] = X + (size_t)g * a.ldx + (pslot ^ ((rho >> 1) & 7)) * 8;
     }
     const int a_rows_needed = BM + ntap - 1 + (POOL ? 1 : 0);
-    const __bf16* b_src[4];
+    const __bf16* b_src[BQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < BQ; ++q) {
         const int n = (q * NWAVE + wid) * 8 + srow;
         b_src[q] = Bt + (size_t)min(n0 + n, a.N - 1) * a.K + (pslot ^ ((n >> 1) & 7)) * 8;
     }
@@ -102,7 +107,7 @@ conv256_kernel(Conv256Args a) {
         const int koff = j * a.Cin + cs * 64;
         char* dst = Bs + buf * B_BYTES + wid * 1024;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(b_src[q] + koff, dst + q * NWAVE * 1024);
+        for (int q = 0; q < BQ; ++q) glds16(b_src[q] + koff, dst + q * NWAVE * 1024);
     };
 
     // ---------------- MFMA roles
@@ -156,8 +161,8 @@ conv256_kernel(Conv256Args a) {
     };
 
     // ---------------- prologue: tiles 0 .. DIST-1 in flight, tile 0 (and slab 0) awaited.
-    // Every wave issues exactly 4 loads per weight tile and any activation-slab loads BEFORE the
-    // weight tile of the same section, so "all but the newest 4*k loads" always means "all but the
+    // Every wave issues exactly BQ (4 or 2) loads per weight tile and any activation-slab loads BEFORE the
+    // weight tile of the same section, so "all but the newest BQ*k loads" always means "all but the
     // newest k weight tiles": the counted s_waitcnt below needs no other bookkeeping.  The barrier
     // is the raw s_barrier: __syncthreads() would drain the loads that are meant to stay in flight.
     stageA(0, 0);
@@ -165,7 +170,7 @@ conv256_kernel(Conv256Args a) {
 #pragma unroll
     for (int d = 1; d < DIST; ++d)
         if (d < ntiles) stageB(d, d);
-    wait_loads_but(4 * min(DIST - 1, ntiles - 1));
+    wait_loads_but(BQ * min(DIST - 1, ntiles - 1));
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (nslab > 1) stageA(1, 1);
@@ -204,7 +209,7 @@ conv256_kernel(Conv256Args a) {
             if (s == 3) {
                 // every read of tile n is issued: retire them, publish tile n+1 (tiles n+2 .. n+DIST
                 // stay in flight), recycle tile n's buffer for tile n+1+DIST
-                wait_loads_but(4 * min(DIST - 1, ntiles - 2 - n));
+                wait_loads_but(BQ * min(DIST - 1, ntiles - 2 - n));
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 have_next = n + 1 < ntiles;
@@ -302,16 +307,18 @@ conv256_kernel(Conv256Args a) {
     }
 }
 
-template <int WN, bool POOL> int launch(const Conv256Args& a, hipStream_t st) {
-    constexpr int NBUF = WN == 4 ? 3 : 4;              // 32 KB / 16 KB weight tiles: 131 KB / 100 KB of LDS
-    constexpr int LDS = 2 * A_BYTES + NBUF * 64 * WN * 128;
+template <int WN, bool POOL, int WM> int launch(const Conv256Args& a, hipStream_t st) {
+    constexpr int NBUF = WN == 4 ? 3 : 4;              // 32 KB / 16 KB weight tiles
+    constexpr int BM = 64 * WM;
+    constexpr int LDS = 2 * a_rows(WM) * 128 + NBUF * 64 * WN * 128;
+    static_assert(LDS <= 160 * 1024 && BM * (64 * WN * 2 + 16) <= LDS, "LDS budget (K loop, epilogue tile)");
     static bool attr_done = false;
     if (!attr_done) {
-        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv256_kernel<WN, POOL, NBUF>),
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(conv256_kernel<WN, POOL, NBUF, WM>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv256_kernel<WN, POOL, NBUF>), dim3((a.M + BM - 1) / BM, a.N / (64 * WN)), dim3(128 * WN), LDS, st, a);
+    hipLaunchKernelGGL((conv256_kernel<WN, POOL, NBUF, WM>), dim3((a.M + BM - 1) / BM, a.N / (64 * WN)), dim3(64 * WM * WN), LDS, st, a);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }
@@ -320,6 +327,11 @@ template <int WN, bool POOL> int launch(const Conv256Args& a, hipStream_t st) {
 
 int vc_launch_conv256(const Conv256Args& a, hipStream_t st) {
     const bool wide = (a.N % 256) == 0;
-    if (a.pool) return wide ? launch<4, true>(a, st) : launch<2, true>(a, st);
-    return wide ? launch<4, false>(a, st) : launch<2, false>(a, st);
+    // 128-column tiles: 256 rows per block (eight waves, half the weight traffic per frame) once there are enough
+    // rows; a launch's CU time, not its block count, is what it costs with several batches in flight.
+    // VC_CONV256_WM=2 keeps the 128-row blocks (A/B).
+    const char* e = getenv("VC_CONV256_WM");
+    const bool tall = !wide && a.M >= 2048 && !(e && e[0] == '2');
+    if (a.pool) return wide ? launch<4, true, 2>(a, st) : (tall ? launch<2, true, 4>(a, st) : launch<2, true, 2>(a, st));
+    return wide ? launch<4, false, 2>(a, st) : (tall ? launch<2, false, 4>(a, st) : launch<2, false, 2>(a, st));
 }

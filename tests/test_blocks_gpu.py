@@ -111,7 +111,10 @@ def test_conv1d_banks(dtype, K, cin):
 
 
 @pytest.mark.parametrize('N,T,cin,f,size,pool,with_res', [(2, 400, 512, 128, 3, 2, False), (3, 100, 384, 256, 3, 0, True),
-                                                         (1, 333, 1024, 128, 1, 0, False), (5, 77, 256, 256, 5, 2, True)])
+                                                         (1, 333, 1024, 128, 1, 0, False), (5, 77, 256, 256, 5, 2, True),
+                                                         # >= 2048 rows x 128 columns: the 256-row blocks (eight waves)
+                                                         (6, 400, 1024, 128, 3, 0, False), (9, 250, 512, 128, 3, 2, True),
+                                                         (11, 197, 256, 128, 7, 0, True)])
 def test_conv1d_deep_pipeline_kernel(N, T, cin, f, size, pool, with_res, monkeypatch):
     """Long-K single-filter bf16 convolutions run on vc_conv256.hip (LDS-direct operand loads, the
     max-pool taken on the fragments).  Bit-identical to conv_kernel / gemm_kernel and within the bf16
