@@ -165,6 +165,11 @@ conv256_kernel(Conv256Args a) {
     // weight tile of the same section, so "all but the newest BQ*k loads" always means "all but the
     // newest k weight tiles": the counted s_waitcnt below needs no other bookkeeping.  The barrier
     // is the raw s_barrier: __syncthreads() would drain the loads that are meant to stay in flight.
+    // With ONE tap per slab the activation slab of tile n+2 is requested in tile n's section, right before weight
+    // tile n+1+DIST, and is needed one section later -- it would still be among the "newest 2 weight tiles" worth
+    // of loads.  Only the newest weight tile may then stay in flight across a barrier.  (taps >= 2: a slab is
+    // requested when the previous one is entered and has aged past the count by the time it is read.)
+    const int keep = ntap == 1 ? DIST - 2 : DIST - 1;
     stageA(0, 0);
     stageB(0, 0);
 #pragma unroll
@@ -209,7 +214,7 @@ conv256_kernel(Conv256Args a) {
             if (s == 3) {
                 // every read of tile n is issued: retire them, publish tile n+1 (tiles n+2 .. n+DIST
                 // stay in flight), recycle tile n's buffer for tile n+1+DIST
-                wait_loads_but(BQ * min(DIST - 1, ntiles - 2 - n));
+                wait_loads_but(BQ * min(keep, ntiles - 2 - n));
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 have_next = n + 1 < ntiles;

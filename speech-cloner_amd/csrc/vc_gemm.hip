@@ -876,7 +876,7 @@ bool proj256_ok(const vc_gemm_desc* d) {
     const char* e = std::getenv("VC_PROJ256");
     if ((e && e[0] == '0') || d->dtype != VC_BF16 || d->mode != VC_GEMM_PLAIN || d->n_groups != 1) return false;
     const vc_gemm_group& g = d->groups[0];
-    if (d->N != 256 || d->Cin % 64 || d->M < 1024 || g.taps < 1 || g.taps > 32 || g.taps * d->Cin < 4096) return false;
+    if (d->N != 256 || d->Cin % 64 || d->M < 1024 || g.taps < 2 || g.taps > 32 || g.taps * d->Cin < 4096) return false;
     if (d->d_pro_scale || d->pro_relu || d->pro_pool || d->d_R || d->out_f32 || d->drop_keep > 0.0f || d->epi_pool) return false;
     if (d->act != VC_ACT_NONE && d->act != VC_ACT_RELU) return false;
     if ((reinterpret_cast<uintptr_t>(d->d_C) & 15) || d->ldx % 8 || d->ldc % 8 || g.c_off % 8) return false;

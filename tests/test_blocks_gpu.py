@@ -114,7 +114,9 @@ def test_conv1d_banks(dtype, K, cin):
                                                          (1, 333, 1024, 128, 1, 0, False), (5, 77, 256, 256, 5, 2, True),
                                                          # >= 2048 rows x 128 columns: the 256-row blocks (eight waves)
                                                          (6, 400, 1024, 128, 3, 0, False), (9, 250, 512, 128, 3, 2, True),
-                                                         (11, 197, 256, 128, 7, 0, True)])
+                                                         (11, 197, 256, 128, 7, 0, True),
+                                                         # one tap per slab (dense layers): the slab is needed one section after its request
+                                                         (7, 400, 2048, 128, 1, 0, False), (2, 400, 1024, 256, 1, 0, True), (1, 130, 4096, 128, 1, 0, False)])
 def test_conv1d_deep_pipeline_kernel(N, T, cin, f, size, pool, with_res, monkeypatch):
     """Long-K single-filter bf16 convolutions run on vc_conv256.hip (LDS-direct operand loads, the
     max-pool taken on the fragments).  Bit-identical to conv_kernel / gemm_kernel and within the bf16
