@@ -140,9 +140,11 @@ def test_conv1d_deep_pipeline_kernel(N, T, cin, f, size, pool, with_res, monkeyp
         monkeypatch.setenv('VC_CONV256', '1')
         poison_gpu_state()
         y = modules.conv1d(xd, **kw)
+        again = [modules.conv1d(xd, **kw) for _ in range(12)]             # a rare ordering bug shows as a rare mismatch
     torch.cuda.synchronize()
     assert not torch.isnan(y.float()).any()
     assert torch.equal(y, y_old)
+    assert all(torch.equal(y, z) for z in again)
     w = {k: v.cpu().double() for k, v in st.vars.items()}
     cast = lambda t: t.bfloat16().double()
     xin = mo.max_pool_2_same(cast(x)) if pool else cast(x)
