@@ -116,10 +116,20 @@ class VariableStore:
         self._cache.clear()
 
     def cached(self, key, fn):
+        """Kernel-layout copy of weights, built on first use.  The build runs on the CURRENT stream, later
+        users may run on any stream: a copy built on a side stream (first decoder.predict chunk after a
+        restore, with n_streams > 1) is waited for here, once, so that a chunk issued right afterwards on
+        another stream cannot read it half-built.  Builds on the default stream need no wait: every side
+        stream is ordered behind the default stream before it gets work."""
         v = self._cache.get(key)
         if v is None:
             v = fn()
             self._cache[key] = v
+            torch = _torch()
+            if torch.cuda.is_available():
+                cur = torch.cuda.current_stream()
+                if cur != torch.cuda.default_stream():
+                    cur.synchronize()
         return v
 
 

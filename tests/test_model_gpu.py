@@ -184,3 +184,23 @@ def test_full_batches_in_flight_are_bit_identical(golden_dir):
     b = dec.predict(small, batch_size=1, n_streams=8)
     for u_, v_ in zip(a, b):
         assert np.array_equal(u_, v_)
+
+
+def test_first_use_on_side_streams_builds_weight_copies_safely(golden_dir):
+    """The kernel-layout weight copies are built on first use, on whatever stream the first chunk runs on; a
+    second chunk on another stream must not read them half-built: the very first predict after a restore, with
+    streams, already equals the sequential result."""
+    from encoder import encoder_spec_phn
+    from decoder import decoder_specs
+    g = np.load(os.path.join(golden_dir, 'encoder_fwd.npz'))
+    dec_cfg = json.load(open(os.path.join(HP, 'decoder_cfg_d.json')))
+    dec_cfg['is_training'] = False
+    x = np.concatenate([g['x'] * s for s in (1.0, 0.7, 0.4, 0.2)], 0)           # 12 windows -> 6 chunks of 2
+    outs = []
+    for n_streams in (3, 1):
+        enc = encoder_spec_phn(_enc_cfg(golden_dir, 'bfloat16'), None)
+        dec = decoder_specs(dec_cfg, None, enc)                                   # fresh stores: every cache empty
+        torch.cuda.synchronize()
+        outs.append(dec.predict(x, batch_size=2, n_streams=n_streams))
+    for u_, v_ in zip(*outs):
+        assert not np.isnan(u_).any() and np.array_equal(u_, v_)
