@@ -428,10 +428,10 @@ int vc_cbhg_front(const vc_cbhg_front_desc* desc, void* stream);
  * 64 -> 256 -> 128 and 80 -> 512 -> 256; vc_prenet_chain_supported() tells, other shapes take two vc_conv_gemm
  * launches): the intermediate stays in registers.  d_pk1 = vc_mfma_pack(W1^T [units1, cin_padded], chained = 0),
  * d_pk2 = vc_mfma_pack(W2^T [units2, units1], chained = 1); d_b1 [units1], d_b2 [units2] float32;
- * d_X [M, ldx] bf16 (padding columns zero), d_Y [M, ldy] bf16.  Same bf16 rounding points as the two launches,
+ * d_X [M, ldx] bf16, or float32 with x_f32 = 1 (converted on load: y_mel of the previous stage), padding columns zero; d_Y [M, ldy] bf16.  Same bf16 rounding points as the two launches,
  * float32 sums in the same K order (bit-identical in practice, tested to 1e-2). */
 int vc_prenet_chain_supported(int32_t cin_padded, int32_t units1, int32_t units2);
-int vc_prenet_chain(const void* d_X, int32_t M, int32_t ldx, int32_t cin_padded, int32_t units1, int32_t units2,
+int vc_prenet_chain(const void* d_X, int32_t x_f32, int32_t M, int32_t ldx, int32_t cin_padded, int32_t units1, int32_t units2,
                     const void* d_pk1, const float* d_b1, const void* d_pk2, const float* d_b2, void* d_Y, int32_t ldy,
                     void* stream);
 

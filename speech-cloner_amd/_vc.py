@@ -139,7 +139,7 @@ _SIGS = {
                                    _P, _P, C.c_int32, _P, C.c_int32, _P]),
     'vc_mfma_pack': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     'vc_prenet_chain_supported': (C.c_int, [C.c_int32] * 3),
-    'vc_prenet_chain': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
+    'vc_prenet_chain': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P]),
     'vc_cbhg_front_coef_floats': (C.c_int32, []),
     'vc_cbhg_front_supported': (C.c_int, [C.c_int32] * 8),
     'vc_cbhg_front': (C.c_int, [C.POINTER(CbhgFrontDesc), _P]),

@@ -443,7 +443,7 @@ cbhg_small_kernel(CbhgSmallArgs a) {
 // output tile goes through a wave-private LDS tile for whole-row stores.  Every weight fragment is used for
 // ONE MFMA per wave, so the launch is bound by the L2 -> CU weight stream (0.34 MB per wave), not by MFMA.
 struct PrenetArgs {
-    const __bf16* X; int32_t M, ldx;
+    const void* X; int32_t x_f32, M, ldx;
     const bf16x8 *pk1, *pk2;
     const float *b1, *b2;
     __bf16* Y; int32_t ldy;
@@ -464,8 +464,17 @@ prenet_chain_kernel(PrenetArgs a) {
     char* const tile = smem + w * 32 * PITCH;
 
     bf16x8 xb[KS1];
-    {
-        const __bf16* xr = a.X + (size_t)row * a.ldx + 8 * lh;
+    if (a.x_f32) {                                     // float32 features (y_mel of the previous stage): converted on load
+        const float* xr = static_cast<const float*>(a.X) + (size_t)row * a.ldx + 8 * lh;
+        f32x4 lo[KS1], hi[KS1];
+#pragma unroll
+        for (int s = 0; s < KS1; ++s) { lo[s] = *reinterpret_cast<const f32x4*>(xr + 16 * s); hi[s] = *reinterpret_cast<const f32x4*>(xr + 16 * s + 4); }
+#pragma unroll
+        for (int s = 0; s < KS1; ++s)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { xb[s][e] = (__bf16)lo[s][e]; xb[s][4 + e] = (__bf16)hi[s][e]; }
+    } else {
+        const __bf16* xr = static_cast<const __bf16*>(a.X) + (size_t)row * a.ldx + 8 * lh;
 #pragma unroll
         for (int s = 0; s < KS1; ++s) xb[s] = *reinterpret_cast<const bf16x8*>(xr + 16 * s);
     }
@@ -593,17 +602,17 @@ int vc_prenet_chain_supported(int32_t cin_padded, int32_t units1, int32_t units2
     return (cin_padded == 64 && units1 == 256 && units2 == 128) || (cin_padded == 80 && units1 == 512 && units2 == 256);
 }
 
-int vc_prenet_chain(const void* d_X, int32_t M, int32_t ldx, int32_t cin_padded, int32_t units1, int32_t units2,
+int vc_prenet_chain(const void* d_X, int32_t x_f32, int32_t M, int32_t ldx, int32_t cin_padded, int32_t units1, int32_t units2,
                     const void* d_pk1, const float* d_b1, const void* d_pk2, const float* d_b2, void* d_Y, int32_t ldy,
                     void* stream) {
     VC_REQUIRE(d_X && d_pk1 && d_b1 && d_pk2 && d_b2 && d_Y && M > 0, "vc_prenet_chain: NULL argument or M <= 0");
     VC_REQUIRE(vc_prenet_chain_supported(cin_padded, units1, units2), "vc_prenet_chain: unsupported shape %d -> %d -> %d", cin_padded, units1, units2);
-    VC_REQUIRE(ldx >= cin_padded && ldx % 8 == 0 && ldy >= units2 && ldy % 8 == 0, "vc_prenet_chain: leading dimensions must be multiples of 8 and cover the rows");
+    VC_REQUIRE(ldx >= cin_padded && ldx % (x_f32 ? 4 : 8) == 0 && ldy >= units2 && ldy % 8 == 0, "vc_prenet_chain: leading dimensions must keep rows 16-byte aligned and cover them");
     VC_REQUIRE(((reinterpret_cast<uintptr_t>(d_X) | reinterpret_cast<uintptr_t>(d_Y) | reinterpret_cast<uintptr_t>(d_pk1) |
                  reinterpret_cast<uintptr_t>(d_pk2) | reinterpret_cast<uintptr_t>(d_b1) | reinterpret_cast<uintptr_t>(d_b2)) & 15) == 0,
                "vc_prenet_chain: operands must be 16-byte aligned");
     PrenetArgs a;
-    a.X = static_cast<const __bf16*>(d_X); a.M = M; a.ldx = ldx;
+    a.X = d_X; a.x_f32 = x_f32 ? 1 : 0; a.M = M; a.ldx = ldx;
     a.pk1 = static_cast<const bf16x8*>(d_pk1); a.pk2 = static_cast<const bf16x8*>(d_pk2);
     a.b1 = d_b1; a.b2 = d_b2; a.Y = static_cast<__bf16*>(d_Y); a.ldy = ldy;
     hipStream_t st = static_cast<hipStream_t>(stream);

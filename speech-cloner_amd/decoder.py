@@ -132,7 +132,8 @@ class decoder_specs:
                     y = modules.dense(out, sd['n_output'], None, name="y_logits", out_f32=True)
                 ys.append(y)
                 cin = sd['n_output']
-                x = modules.convert(y, st.dtype)               # step2's input is y_mel (decoder.py:155)
+                if i + 1 < len(c['steps_v'][:2]):
+                    x = y                                       # step2's input is y_mel (decoder.py:155); prenet converts on load
         return ys[0], ys[1]
 
     def forward(self, x):

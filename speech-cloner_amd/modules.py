@@ -465,7 +465,7 @@ def prenet(inputs, num_units=None, embed_size=256, dropout_rate=0.5, is_training
     store = _store()
     x = _as3(inputs)
     N_, T_, Cx = x.shape
-    if (not is_training and store.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+    if (not is_training and store.dtype == torch.bfloat16 and x.dtype in (torch.bfloat16, torch.float32)
             and os.environ.get('VC_PRENET_CHAIN', '1') != '0'
             and _vc.lib().vc_prenet_chain_supported(Cx, num_units[0], num_units[1])):
         # both layers in one launch, the intermediate never leaves the registers (vc_prenet_chain)
@@ -482,12 +482,12 @@ def prenet(inputs, num_units=None, embed_size=256, dropout_rate=0.5, is_training
                                                                _mfma_pack(bt2, num_units[1], num_units[0], 1)))
         x = x.contiguous()
         out = torch.empty((N_, T_, num_units[1]), dtype=store.dtype, device=x.device)
-        _vc.check(_vc.lib().vc_prenet_chain(x.data_ptr(), N_ * T_, Cx, Cx, num_units[0], num_units[1], pk1.data_ptr(),
+        _vc.check(_vc.lib().vc_prenet_chain(x.data_ptr(), int(x.dtype == torch.float32), N_ * T_, Cx, Cx, num_units[0], num_units[1], pk1.data_ptr(),
                                             b1.data_ptr(), pk2.data_ptr(), b2.data_ptr(), out.data_ptr(), num_units[1],
                                             _vc.current_stream()))
         return out
     with variable_scope(scope):
-        outputs = dense(inputs, num_units[0], 'relu', name="dense1", in_features=in_features)
+        outputs = dense(convert(x, store.dtype), num_units[0], 'relu', name="dense1", in_features=in_features)
         outputs = _dropout(outputs, dropout_rate, is_training)
         outputs = dense(outputs, num_units[1], 'relu', name="dense2")
         outputs = _dropout(outputs, dropout_rate, is_training)

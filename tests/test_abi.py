@@ -65,7 +65,7 @@ def test_fused_launch_shape_queries_and_validation_without_gpu():
     d.n_banks = 16
     rc = lib.vc_cbhg_front(ctypes.byref(d), None)
     assert rc != 0 and b'unsupported shape' in lib.vc_last_error()
-    rc = lib.vc_prenet_chain(None, 128, 80, 80, 512, 256, None, None, None, None, None, 256, None)
+    rc = lib.vc_prenet_chain(None, 0, 128, 80, 80, 512, 256, None, None, None, None, None, 256, None)
     assert rc != 0 and b'vc_prenet_chain' in lib.vc_last_error()
     rc = lib.vc_mfma_pack(None, 32, 16, 16, 0, None, None)
     assert rc != 0 and b'vc_mfma_pack' in lib.vc_last_error()
