@@ -208,6 +208,10 @@ int vc_conv_gemm_epi_pool_supported(const vc_gemm_desc* desc);
  * decoder's first dense can read 16-byte rows) and int32 class ids (first maximum). */
 int vc_softmax_argmax(const float* d_logits, int32_t M, int32_t N, int32_t ldl,
                       void* d_prob, int32_t ldp, int32_t out_dtype, int32_t* d_class, void* stream);
+/* Same, writing the probabilities twice in one launch: float32 (the API's y_pred) and a zero-padded bf16 copy (the
+ * decoder's input, decoder.py:86), identical to two calls of vc_softmax_argmax. */
+int vc_softmax_argmax_dual(const float* d_logits, int32_t M, int32_t N, int32_t ldl, float* d_prob, int32_t ldp,
+                           void* d_prob_bf16, int32_t ldp_bf16, int32_t* d_class, void* stream);
 
 /* Bidirectional GRU recurrence (modules.py:168-204 -> tf.nn.bidirectional_dynamic_rnn over
  * tf.contrib.rnn.GRUCell):  g = sigmoid(xg + h Wg_h);  r,u = split(g) (r first);

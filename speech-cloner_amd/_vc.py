@@ -110,6 +110,7 @@ _SIGS = {
                                          C.c_size_t, _P, C.c_int32]),
     'vc_conv_gemm': (C.c_int, [C.POINTER(GemmDesc), _P]),
     'vc_softmax_argmax': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
+    'vc_softmax_argmax_dual': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P]),
     'vc_gru_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
     'vc_gru_bidir': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P,
                                C.c_size_t, _P]),

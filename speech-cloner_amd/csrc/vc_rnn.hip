@@ -570,7 +570,8 @@ gru_wave_kernel(GruArgs a) {
 
 // ------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
-softmax_argmax_kernel(const float* logits, int M, int N, int ldl, void* prob, int ldp, int out_bf16, int32_t* cls) {
+softmax_argmax_kernel(const float* logits, int M, int N, int ldl, void* prob, int ldp, int out_bf16, int32_t* cls,
+                      __bf16* prob2, int ldp2) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -591,10 +592,14 @@ softmax_argmax_kernel(const float* logits, int M, int N, int ldl, void* prob, in
     for (int c = lane; c < N; c += 64) s += expf(x[c] - mx);
     s = vc::wave_sum(s);
     const float inv = 1.0f / s;
-    for (int c = lane; c < ldp; c += 64) {
+    const int wmax = ldp > ldp2 ? ldp : ldp2;
+    for (int c = lane; c < wmax; c += 64) {
         const float p = c < N ? expf(x[c] - mx) * inv : 0.0f;
-        if (out_bf16) reinterpret_cast<__bf16*>(prob)[(size_t)row * ldp + c] = (__bf16)p;
-        else reinterpret_cast<float*>(prob)[(size_t)row * ldp + c] = p;
+        if (c < ldp) {
+            if (out_bf16) reinterpret_cast<__bf16*>(prob)[(size_t)row * ldp + c] = (__bf16)p;
+            else reinterpret_cast<float*>(prob)[(size_t)row * ldp + c] = p;
+        }
+        if (prob2 && c < ldp2) prob2[(size_t)row * ldp2 + c] = (__bf16)p;      // second, zero-padded bf16 copy
     }
     if (cls && lane == 0) cls[row] = mi;
 }
@@ -678,7 +683,17 @@ int vc_softmax_argmax(const float* d_logits, int32_t M, int32_t N, int32_t ldl, 
     VC_REQUIRE(M > 0 && N > 0 && ldl >= N && ldp >= N, "bad shape M=%d N=%d ldl=%d ldp=%d", M, N, ldl, ldp);
     VC_REQUIRE(out_dtype == VC_F32 || out_dtype == VC_BF16, "bad out_dtype %d", out_dtype);
     hipLaunchKernelGGL(softmax_argmax_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       d_logits, M, N, ldl, d_prob, ldp, out_dtype == VC_BF16, d_class);
+                       d_logits, M, N, ldl, d_prob, ldp, out_dtype == VC_BF16, d_class, static_cast<__bf16*>(nullptr), 0);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_softmax_argmax_dual(const float* d_logits, int32_t M, int32_t N, int32_t ldl, float* d_prob, int32_t ldp,
+                           void* d_prob_bf16, int32_t ldp_bf16, int32_t* d_class, void* stream) {
+    VC_REQUIRE(d_logits && d_prob && d_prob_bf16, "NULL argument");
+    VC_REQUIRE(M > 0 && N > 0 && ldl >= N && ldp >= N && ldp_bf16 >= N, "bad shape M=%d N=%d ldl=%d ldp=%d/%d", M, N, ldl, ldp, ldp_bf16);
+    hipLaunchKernelGGL(softmax_argmax_kernel, dim3((M + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       d_logits, M, N, ldl, static_cast<void*>(d_prob), ldp, 0, d_class, static_cast<__bf16*>(d_prob_bf16), ldp_bf16);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }

@@ -123,10 +123,16 @@ class encoder_spec_phn:
                                            c['dropout_rate'], False, prenet_scope="prenet", scope="CBHG",
                                            use_Cudnn=c['use_Cudnn'], use_lstm=c['use_lstm'])
             y_logits = modules.dense(cbhg_out, c['n_output'], None, name="y_logits", out_f32=True)
-        y_pred, y_cls = modules.softmax_argmax(y_logits)
+        dual = ppg_pad_to is not None and ppg_dtype == torch.bfloat16
+        if dual:                                       # one launch: y_pred and the decoder's padded bf16 input
+            y_pred, y_cls, ppg16 = modules.softmax_argmax_dual(y_logits, ppg_pad_to)
+        else:
+            y_pred, y_cls = modules.softmax_argmax(y_logits)
         out = {'CBHG_out': cbhg_out, 'y_logits': y_logits, 'y_pred': y_pred, 'y_pred_class': y_cls}
         if ppg_pad_to is not None:
-            if ppg_pad_to == c['n_output'] and (ppg_dtype is None or ppg_dtype == torch.float32):
+            if dual:
+                out['ppg'] = ppg16
+            elif ppg_pad_to == c['n_output'] and (ppg_dtype is None or ppg_dtype == torch.float32):
                 out['ppg'] = y_pred
             else:
                 out['ppg'] = modules.softmax_argmax(y_logits, pad_to=ppg_pad_to, out_dtype=ppg_dtype)[0]

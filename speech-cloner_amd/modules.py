@@ -673,6 +673,20 @@ def prenet_CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks
     return _gru_recurrence(xproj, N_, T_, H, wh_fw, wh_bw)
 
 
+def softmax_argmax_dual(logits, pad_to):
+    """softmax_argmax with a second, zero-padded bf16 copy of the probabilities from the same launch
+    (the decoder's input layout).  Returns (prob float32 [N, T, n], class ids, prob bf16 [N, T, pad_to])."""
+    torch = _torch()
+    x = _as3(logits)
+    N_, T_, W = x.shape
+    prob = torch.empty((N_, T_, W), dtype=torch.float32, device=x.device)
+    prob16 = torch.empty((N_, T_, pad_to), dtype=torch.bfloat16, device=x.device)
+    cls = torch.empty((N_, T_), dtype=torch.int32, device=x.device)
+    _vc.check(_vc.lib().vc_softmax_argmax_dual(x.data_ptr(), N_ * T_, W, W, prob.data_ptr(), W, prob16.data_ptr(), pad_to,
+                                               cls.data_ptr(), _vc.current_stream()))
+    return prob, cls, prob16
+
+
 def create_stage_variables(store, scope, in_features, embed_size, num_conv_banks, num_highwaynet_blocks, n_output):
     """Create (if absent) every variable of one prenet -> CBHG -> dense(n_output) stage under
     ``scope`` with TensorFlow's default initialisers, in graph order, WITHOUT launching kernels

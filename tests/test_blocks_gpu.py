@@ -447,3 +447,16 @@ def test_wide_projection_on_the_bank_tiles(N, T, cin, k, monkeypatch):
     torch.cuda.synchronize()
     assert not torch.isnan(y.float()).any()
     assert torch.equal(y, y_ref)
+
+
+def test_softmax_dual_output_equals_two_launches():
+    """vc_softmax_argmax_dual: float32 posteriors + zero-padded bf16 copy in one launch == two launches."""
+    import modules
+    rng = np.random.RandomState(12)
+    lg = torch.from_numpy((3.0 * rng.standard_normal((3, 77, 61))).astype(np.float32)).cuda()
+    p, c = modules.softmax_argmax(lg)
+    p16, c16 = modules.softmax_argmax(lg, pad_to=64, out_dtype=torch.bfloat16)
+    q, d, q16 = modules.softmax_argmax_dual(lg, 64)
+    torch.cuda.synchronize()
+    assert torch.equal(p, q) and torch.equal(c, d) and torch.equal(c, c16) and torch.equal(p16, q16)
+    assert q16.shape == (3, 77, 64) and float(q16[..., 61:].abs().max()) == 0.0
