@@ -42,6 +42,26 @@ const char* vc_last_error(void);
 /* Name of the gfx target the code object was built for ("gfx950"). */
 const char* vc_target_arch(void);
 
+/* Kernel-selection options.  The library never reads the process environment; the only way to steer which of
+ * two equivalent HIP kernels a launch takes (A/B measurements, regression tests) is this call.  Values: -1 = the
+ * library's own choice (default).  Names:
+ *   "bank256"        0 = filter banks on conv_kernel instead of bank256_kernel
+ *   "bank256_xcd"    0 = plain 2-D grid, 1 = whole filter-width pairs per XCD, 2 = pairs split over two XCDs
+ *   "conv256"        0 = long-K single filters on conv_kernel / gemm_kernel
+ *   "conv256_min_k"  shortest K that takes conv256_kernel (default 384)
+ *   "conv256_wm"     2 = keep 128-row blocks for 128-column launches
+ *   "proj256"        0 = the 256-channel k = 3 projection on conv256_kernel instead of the bank tiles
+ *   "wgrad_xcd"      0 = weight-gradient tiles dealt round-robin to the XCDs
+ *   "gru_mfma"       0 = VALU recurrence always, 1 = MFMA recurrence always (default: from 32 sequences up)
+ *   "cbhg_front_mi"  4 = 128-row blocks in the fused encoder front
+ * All alternatives compute the same function (tests compare them).  Three more names, "ablate_bank256",
+ * "ablate_bank256_only" and "ablate_cbhg_front", skip parts of a kernel for timing and give WRONG results: they
+ * exist only in a library built with -DVC_ABLATE (tools/build_ablate.sh; vc_ablate_build() returns 1 there) and
+ * are rejected with VC_ERR_INVALID by the shipped build.  Options are process-global; set them between launches. */
+int vc_set_option(const char* name, int value);
+int vc_get_option(const char* name, int* value);
+int vc_ablate_build(void);
+
 /* ------------------------------------------------------------------------------------------
  * Signal front-end: audio_lib.calc_MFCC_input  (/root/reference/audio_lib.py:89-244)
  *   amplitude normalisation (:125-126) -> pre-emphasis FIR (:12-28,:129-133) -> centred,

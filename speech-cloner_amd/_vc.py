@@ -3,14 +3,16 @@
 This is the only place Python touches the native library.  There is NO CPU fallback: if the
 library is missing or an entry point fails, an exception is raised (``VCError``).
 """
+import contextlib
 import ctypes as C
 import os
 import threading
 
-# Work that is independent (window chunks in decoder.predict(n_streams=...), consecutive batches) is pipelined over
-# HIP streams; the runtime folds streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and two streams sharing a
-# queue serialise.  Takes effect only if set before the HIP runtime initialises (the first GPU call of the process).
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+# Caller requirement (documented in INTEGRATION.md, not enforced here -- this module never writes os.environ):
+# independent work (window chunks in decoder.predict(n_streams=...), consecutive batches) is pipelined over HIP streams,
+# and the HIP runtime folds streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); two streams sharing a queue
+# serialise.  A caller that keeps more than ~3 batches in flight exports GPU_MAX_HW_QUEUES=16 BEFORE the process makes
+# its first GPU call (bench.py does); results do not depend on it.
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VC_LIB_PATH', os.path.join(_HERE, 'libvc_hip.so'))   # override: kernel A/B experiments
@@ -95,6 +97,9 @@ _SIGS = {
     'vc_version': (C.c_int, []),
     'vc_last_error': (C.c_char_p, []),
     'vc_target_arch': (C.c_char_p, []),
+    'vc_set_option': (C.c_int, [C.c_char_p, C.c_int]),
+    'vc_get_option': (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    'vc_ablate_build': (C.c_int, []),
     'vc_frontend_host_tables': (C.c_int, [C.POINTER(FrontendCfg), _P, _P]),
     'vc_frontend_plan_create': (C.c_int, [C.POINTER(FrontendCfg), _P, C.POINTER(_P)]),
     'vc_frontend_plan_destroy': (None, [_P]),
@@ -179,6 +184,30 @@ def lib():
             fn.argtypes = args
         _lib = h
     return _lib
+
+
+def set_option(name, value):
+    """vc_set_option (include/vc_hip.h): pick between equivalent HIP kernels; -1 restores the default."""
+    check(lib().vc_set_option(name.encode(), int(value)))
+
+
+def get_option(name):
+    v = C.c_int(0)
+    check(lib().vc_get_option(name.encode(), C.byref(v)))
+    return v.value
+
+
+@contextlib.contextmanager
+def options(**kw):
+    """with _vc.options(gru_mfma=1): ...  -- sets, then restores, library options."""
+    old = {k: get_option(k) for k in kw}
+    try:
+        for k, v in kw.items():
+            set_option(k, v)
+        yield
+    finally:
+        for k, v in old.items():
+            set_option(k, v)
 
 
 def check(rc):

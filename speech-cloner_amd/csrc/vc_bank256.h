@@ -22,7 +22,7 @@ struct Bank256Args {
     // per XCD (workgroup id & 7) up to 4 segments of work, walked in order: row tiles [first, first + count) of a pair
     int16_t seg_pair[8][4], seg_first[8][4], seg_count[8][4];
     int32_t pool;         // store max(y[t], y[t+1]) per window: row tiles advance by 255 frames
-    int32_t dbg;          // measurement hook (VC_BANK256_DBG): 1 = skip the K loop, 2 = skip the stores, 4 = no loads inside the K loop (wrong results)
+    int32_t dbg;          // -DVC_ABLATE builds only (option ablate_bank256): 1 = skip the K loop, 2 = skip the stores, 4 = no loads inside the K loop, 8 = no barrier (timing only, wrong results); ignored by the shipped build
     Bank256Pair p[16];
 };
 

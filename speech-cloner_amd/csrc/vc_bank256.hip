@@ -28,6 +28,14 @@
 
 namespace {
 
+// Timing-only ablations (wrong results) are compiled in with -DVC_ABLATE alone (tools/build_ablate.sh); the shipped
+// library has no such path: ABL() is the constant false.
+#ifdef VC_ABLATE
+#define ABL(mask) ((a.dbg & (mask)) != 0)
+#else
+#define ABL(mask) false
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -217,13 +225,13 @@ bank256_kernel(Bank256Args a) {
             if (s == 3) {
                 // every read of tile n has been issued; retire them, publish tile n+1, recycle tile n's buffer
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                if (!(a.dbg & 8)) __syncthreads();
-                if (n + 2 < ntiles && !(a.dbg & 4)) stageB(n + 2, n & 1);
+                if (!ABL(8)) __syncthreads();
+                if (n + 2 < ntiles && !ABL(4)) stageB(n + 2, n & 1);
                 have_next = n + 1 < ntiles;
                 if (have_next) {
                     const int cs1 = (n + 1) / ntap;
                     // first tile of a slab: bring in the slab after it (its buffer was last read a slab ago)
-                    if ((n + 1) - cs1 * ntap == 0 && cs1 + 1 < nslab && !(a.dbg & 4)) stageA(cs1 + 1, (cs1 + 1) & 1);
+                    if ((n + 1) - cs1 * ntap == 0 && cs1 + 1 < nslab && !ABL(4)) stageA(cs1 + 1, (cs1 + 1) & 1);
                     jn = tap_setup(n + 1);
                 }
                 nb = (n + 1) & 1;
@@ -308,7 +316,7 @@ bank256_kernel(Bank256Args a) {
         }
         j = jn;
     };
-    const int nrun = (a.dbg & 1) ? 0 : ntiles;
+    const int nrun = ABL(1) ? 0 : ntiles;
     for (int n = 0; n < nrun; ++n) {
         tile(n, !(j >= J_lo && j < J_hi));
     }
@@ -366,7 +374,7 @@ bank256_kernel(Bank256Args a) {
                 vv = (min(gm, a.M - 1) % a.T == a.T - 1) ? vv : mx;
             }
             // streaming store: the 210 MB output must not displace the weight tiles from L2
-            if (gm < a.M && row < nrows && !(a.dbg & 2))
+            if (gm < a.M && row < nrows && !ABL(2))
                 __builtin_nontemporal_store(vv, reinterpret_cast<bf16x8*>(C + (size_t)gm * a.ldc + (half ? pr.c_off1 : pr.c_off0) + l16 * 8));
         }
     }
@@ -384,8 +392,8 @@ int vc_launch_bank256(const Bank256Args& a, hipStream_t st) {
     const int stride = a.pool ? BM - 1 : BM;
     const int ntm = (a.M + stride - 1) / stride;
     Bank256Args b = a;
-    const char* env = getenv("VC_BANK256_XCD");
-    b.xcd_tiles = (a.n_pairs >= 8 && a.n_pairs <= 16 && ntm < 32000 && !(env && env[0] == '0')) ? ntm : 0;
+    const int xcd_mode = vc::opt(vc::OPT_BANK256_XCD);     // 0 plain grid, 1 whole pairs per XCD, else (default) split pairs
+    b.xcd_tiles = (a.n_pairs >= 8 && a.n_pairs <= 16 && ntm < 32000 && xcd_mode != 0) ? ntm : 0;
     if (b.xcd_tiles > 0) {
         // Work lists per XCD.  Cost of a row tile of pair p ~ (wider taps) * slabs * 1.3 us + 10 us, 32 CUs per
         // XCD take tiles in list order.  One pair per XCD pairing (rank x with rank 15 - x, whole pairs) balances
@@ -394,10 +402,10 @@ int vc_launch_bank256(const Bank256Args& a, hipStream_t st) {
         // With 16 pairs every pair is therefore split over TWO XCDs and every XCD gets halves of four pairs: one
         // heavy, two medium, one light (ranks s, 7 - s, 8 + s, 15 - s), heaviest first, so short tiles fill the
         // tail: 5 % over the ideal in the model, at two L2 fetches per weight tile instead of one (eight without
-        // this mapping).  VC_BANK256_XCD=1 selects the whole-pair form (A/B).
+        // this mapping).  vc_set_option("bank256_xcd", 1) selects the whole-pair form (A/B).
         for (int x = 0; x < 8; ++x)
             for (int sg = 0; sg < 4; ++sg) b.seg_pair[x][sg] = b.seg_first[x][sg] = b.seg_count[x][sg] = 0;
-        const bool split = a.n_pairs == 16 && !(env && env[0] == '1');
+        const bool split = a.n_pairs == 16 && xcd_mode != 1;
         int max_slots = 0;
         for (int x = 0; x < 8; ++x) {
             int slots = 0;

@@ -36,6 +36,13 @@
 
 namespace {
 
+// Timing-only ablations (wrong results) exist in -DVC_ABLATE builds alone (tools/build_ablate.sh).
+#ifdef VC_ABLATE
+#define ABL(mask) ((a.dbg & (mask)) != 0)
+#else
+#define ABL(mask) false
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -57,7 +64,7 @@ struct CbhgSmallArgs {
     const bf16x8* pk_hw[CS_MAX_HW];
     const float* coef;             // CO_TOTAL floats, layout CO_* below
     float* P; int32_t ldp;
-    int32_t dbg;                   // VC_CBHG_FRONT_DBG ablations (timing only, wrong results): 1 no bank/proj1 phases, 2 no proj1 part, 4 no bank MFMAs, 8 no tail
+    int32_t dbg;                   // -DVC_ABLATE builds only (option ablate_cbhg_front) (timing only, wrong results): 1 no bank/proj1 phases, 2 no proj1 part, 4 no bank MFMAs, 8 no tail
 };
 
 __device__ __forceinline__ f32x16 zero16() {
@@ -236,7 +243,7 @@ cbhg_small_kernel(CbhgSmallArgs a) {
     bf16x8 wt2[NTC * KSP2];                           // second projection's weights (requested in the last phase)
 #pragma unroll
     for (int k = 1; k <= KB; ++k) {
-        if (a.dbg & 1) break;
+        if (ABL(1)) break;
         const int nks = bank_ksteps(k), pad_l = (k - 1) / 2;
         bf16x8 wcur[MAXB];
 #pragma unroll
@@ -254,7 +261,7 @@ cbhg_small_kernel(CbhgSmallArgs a) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) bacc[mi] = zero16();
         const char* prow = Pt + (li - pad_l) * CS_PITCH + lh * 16;
-        if (!(a.dbg & 4))
+        if (!ABL(4))
 #pragma unroll
         for (int s = 0; s < nks; ++s) {
 #pragma unroll
@@ -278,7 +285,7 @@ cbhg_small_kernel(CbhgSmallArgs a) {
         }
         wave_lds_fence();
         const bf16x8 zero8 = {};
-        if (!(a.dbg & 2))
+        if (!ABL(2))
 #pragma unroll
         for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -347,7 +354,7 @@ cbhg_small_kernel(CbhgSmallArgs a) {
         }
     __syncthreads();
 
-    if (!roww || (a.dbg & 8)) return;                  // no barrier below this line
+    if (!roww || ABL(8)) return;                  // no barrier below this line
     // =================================================================== second projection + residual
     bf16x4 ev[NTC][4];
     {
@@ -654,11 +661,12 @@ int vc_cbhg_front(const vc_cbhg_front_desc* d, void* stream) {
     }
     a.P = d->d_xproj; a.ldp = d->ldp;
     // frame tiles per block: 2 (64 rows, two resident blocks per CU hide each other's epilogues and LDS
-    // round trips) or 4 (128 rows, half the weight traffic per frame); VC_CBHG_FRONT_MI overrides (A/B)
-    const char* dbg = std::getenv("VC_CBHG_FRONT_DBG");
-    a.dbg = dbg ? std::atoi(dbg) : 0;
-    const char* e = std::getenv("VC_CBHG_FRONT_MI");
-    const int mi = (e && e[0] == '4') ? 4 : 2;
+    // round trips) or 4 (128 rows, half the weight traffic per frame); vc_set_option("cbhg_front_mi", 4) overrides (A/B)
+    a.dbg = 0;
+#ifdef VC_ABLATE
+    a.dbg = vc::opt(vc::OPT_ABLATE_CBHG_FRONT) > 0 ? vc::opt(vc::OPT_ABLATE_CBHG_FRONT) : 0;
+#endif
+    const int mi = vc::opt(vc::OPT_CBHG_FRONT_MI) == 4 ? 4 : 2;
     const int maxtf = 32 * mi - HL - 6;
     a.tiles_per_win = (d->T + maxtf - 1) / maxtf;
     a.TF = (d->T + a.tiles_per_win - 1) / a.tiles_per_win;

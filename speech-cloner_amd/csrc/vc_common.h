@@ -25,6 +25,27 @@ int set_error(int code, const char* fmt, ...);
 
 constexpr int WAVE = 64;
 
+// Kernel-selection options (vc_set_option / vc_get_option, include/vc_hip.h).  -1 = the library's own choice.
+// They pick between HIP kernels that compute the SAME function (A/B measurements, regression tests); nothing in
+// the library reads the process environment.  The result-corrupting ablation switches exist only in builds made
+// with -DVC_ABLATE (tools/build_ablate.sh), never in the shipped libvc_hip.so.
+enum Option {
+    OPT_BANK256 = 0,      // 0: filter banks on conv_kernel instead of bank256_kernel
+    OPT_BANK256_XCD,      // 0: plain 2-D grid, 1: whole pairs per XCD, 2: pairs split over two XCDs (default)
+    OPT_CONV256,          // 0: long-K single filters on conv_kernel / gemm_kernel instead of conv256_kernel
+    OPT_CONV256_MINK,     // shortest K that takes conv256_kernel (default 384)
+    OPT_CONV256_WM,       // 2: keep 128-row blocks for 128-column launches (default: 256 rows from 2,048 rows up)
+    OPT_PROJ256,          // 0: 256-channel long-K projection on conv256_kernel instead of the bank tiles
+    OPT_WGRAD_XCD,        // 0: weight-gradient tiles dealt round-robin instead of group-per-XCD
+    OPT_GRU_MFMA,         // 0: VALU recurrence always, 1: MFMA recurrence always (default: from 32 sequences up)
+    OPT_CBHG_FRONT_MI,    // 4: 128-row blocks in cbhg_small_kernel (default 2)
+    OPT_ABLATE_BANK256,   // -DVC_ABLATE only: bit mask, see vc_bank256.h
+    OPT_ABLATE_BANK256_ONLY,   // -DVC_ABLATE only: launch one pair alone
+    OPT_ABLATE_CBHG_FRONT,     // -DVC_ABLATE only: bit mask, see vc_cbhg_small.hip
+    OPT_COUNT
+};
+int opt(Option o);        // current value, -1 if unset
+
 #if defined(__HIPCC__)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -169,7 +169,16 @@ conv256_kernel(Conv256Args a) {
     // tile n+1+DIST, and is needed one section later -- it would still be among the "newest 2 weight tiles" worth
     // of loads.  Only the newest weight tile may then stay in flight across a barrier.  (taps >= 2: a slab is
     // requested when the previous one is entered and has aged past the count by the time it is read.)
+    // INVARIANT of every counted wait below: the loads allowed to stay in flight were all ISSUED AFTER the newest
+    // operand the next tile reads.  In the steady state that is `keep` weight tiles; at the tail the weight tiles
+    // run out first, so the count is clamped by the tiles that were really requested after that operand:
+    //   taps >= 2: after weight tile n+1 come tiles n+2 .. min(n+DIST, ntiles-1)        -> ntiles - 2 - n
+    //              (a slab is followed by >= min(taps, tiles left) weight tiles before it is read; taps >= DIST - 1)
+    //   taps == 1: after slab n+1 (requested in section n-1) comes only weight tile n+DIST -> ntiles - DIST - n,
+    //              i.e. vmcnt(0) from n = ntiles - DIST on (the slab's own loads are the newest ones there).
     const int keep = ntap == 1 ? DIST - 2 : DIST - 1;
+    const int tail0 = ntap == 1 ? ntiles - DIST : ntiles - 2;          // in-flight tiles allowed at section n: tail0 - n
+    static_assert(DIST == 2 || DIST == 3, "the taps >= DIST - 1 argument above assumes 3 or 4 weight buffers");
     stageA(0, 0);
     stageB(0, 0);
 #pragma unroll
@@ -214,7 +223,7 @@ conv256_kernel(Conv256Args a) {
             if (s == 3) {
                 // every read of tile n is issued: retire them, publish tile n+1 (tiles n+2 .. n+DIST
                 // stay in flight), recycle tile n's buffer for tile n+1+DIST
-                wait_loads_but(BQ * min(keep, ntiles - 2 - n));
+                wait_loads_but(BQ * max(0, min(keep, tail0 - n)));
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 have_next = n + 1 < ntiles;
@@ -334,9 +343,8 @@ int vc_launch_conv256(const Conv256Args& a, hipStream_t st) {
     const bool wide = (a.N % 256) == 0;
     // 128-column tiles: 256 rows per block (eight waves, half the weight traffic per frame) once there are enough
     // rows; a launch's CU time, not its block count, is what it costs with several batches in flight.
-    // VC_CONV256_WM=2 keeps the 128-row blocks (A/B).
-    const char* e = getenv("VC_CONV256_WM");
-    const bool tall = !wide && a.M >= 2048 && !(e && e[0] == '2');
+    // vc_set_option("conv256_wm", 2) keeps the 128-row blocks (A/B).
+    const bool tall = !wide && a.M >= 2048 && vc::opt(vc::OPT_CONV256_WM) != 2;
     if (a.pool) return wide ? launch<4, true, 2>(a, st) : (tall ? launch<2, true, 4>(a, st) : launch<2, true, 2>(a, st));
     return wide ? launch<4, false, 2>(a, st) : (tall ? launch<2, false, 4>(a, st) : launch<2, false, 2>(a, st));
 }

@@ -814,8 +814,7 @@ template <typename T, int MI> int launch_mi(const vc_gemm_desc* d, const KArgs& 
 // The filter-bank launch in its paired 256 x 256 form (vc_bank256.hip): bf16, plain operand, groups
 // (2p+1, 2p+2) taps wide with a common left padding, 128 filters each, BatchNorm/ReLU epilogue.
 bool bank256_ok(const vc_gemm_desc* d) {
-    const char* e = std::getenv("VC_BANK256");           // VC_BANK256=0: A/B switch back to conv_kernel
-    if ((e && e[0] == '0') || d->dtype != VC_BF16 || d->mode != VC_GEMM_PLAIN) return false;
+    if (vc::opt(vc::OPT_BANK256) == 0 || d->dtype != VC_BF16 || d->mode != VC_GEMM_PLAIN) return false;
     if (d->n_groups < 2 || (d->n_groups & 1) || d->n_groups > 32 || d->N != 128 || d->Cin % 64 || d->M < 256) return false;
     if (d->d_pro_scale || d->pro_relu || d->pro_pool || d->d_R || d->out_f32 || d->drop_keep > 0.0f) return false;
     if (d->act != VC_ACT_NONE && d->act != VC_ACT_RELU) return false;
@@ -843,22 +842,19 @@ int launch_bank256(const vc_gemm_desc* d, hipStream_t st) {
         p.extra = 1;
     }
     b.dbg = 0;
-    if (const char* dbg = std::getenv("VC_BANK256_DBG")) b.dbg = std::atoi(dbg);
-    if (const char* only = std::getenv("VC_BANK256_ONLY")) {     // measurement hook: launch one pair alone
-        const int p = std::atoi(only);
-        if (p >= 0 && p < b.n_pairs) { b.p[0] = b.p[p]; b.n_pairs = 1; }
-    }
+#ifdef VC_ABLATE
+    b.dbg = vc::opt(vc::OPT_ABLATE_BANK256) > 0 ? vc::opt(vc::OPT_ABLATE_BANK256) : 0;
+    if (const int p = vc::opt(vc::OPT_ABLATE_BANK256_ONLY); p >= 0 && p < b.n_pairs) { b.p[0] = b.p[p]; b.n_pairs = 1; }
+#endif
     return vc_launch_bank256(b, st);
 }
 
 // Single-filter bf16 convolutions / dense layers with a long K on the deep-pipelined 128-row tiles
 // (vc_conv256.hip): plain operand or non-negative max-pool, N a multiple of 128, taps <= 7.
 bool conv256_ok(const vc_gemm_desc* d) {
-    const char* e = std::getenv("VC_CONV256");           // VC_CONV256=0: A/B switch back to conv_kernel / gemm_kernel
-    if ((e && e[0] == '0') || d->dtype != VC_BF16 || d->mode != VC_GEMM_PLAIN || d->n_groups != 1) return false;
+    if (vc::opt(vc::OPT_CONV256) == 0 || d->dtype != VC_BF16 || d->mode != VC_GEMM_PLAIN || d->n_groups != 1) return false;
     const vc_gemm_group& g = d->groups[0];
-    const char* mk = std::getenv("VC_CONV256_MINK");     // shortest K that takes this kernel (A/B)
-    const int min_k = mk ? std::atoi(mk) : 384;           // measured in the pipelined step: 1024 -> 384 = -0.9 % ms/step (the second k = 3 projections)
+    const int min_k = vc::opt(vc::OPT_CONV256_MINK) > 0 ? vc::opt(vc::OPT_CONV256_MINK) : 384;           // measured in the pipelined step: 1024 -> 384 = -0.9 % ms/step (the second k = 3 projections)
     if (d->N % 128 || d->Cin % 64 || d->M < 128 || g.taps > 7 || g.taps * d->Cin < min_k) return false;
     if (d->d_pro_scale || d->pro_relu || d->pro_pool == 1 || d->out_f32 || d->drop_keep > 0.0f) return false;
     if ((reinterpret_cast<uintptr_t>(d->d_C) & 15) || d->ldx % 8 || d->ldc % 8 || g.c_off % 8) return false;
@@ -871,10 +867,9 @@ bool conv256_ok(const vc_gemm_desc* d) {
 // reads per MFMA instead of conv256_kernel's 1.0 and half the weight traffic per frame.  Only M / 256 workgroups
 // (100 at 64 windows), so ALONE on the chip the launch is slower than conv256_kernel's 200 (0.29 vs 0.23 ms) -- but
 // CU time, not the makespan, is what a launch costs once several batches are in flight:
-// 100 x 0.29 ms against 200 x 0.23 ms.  VC_PROJ256=0 switches it off.
+// 100 x 0.29 ms against 200 x 0.23 ms.  vc_set_option("proj256", 0) switches it off.
 bool proj256_ok(const vc_gemm_desc* d) {
-    const char* e = std::getenv("VC_PROJ256");
-    if ((e && e[0] == '0') || d->dtype != VC_BF16 || d->mode != VC_GEMM_PLAIN || d->n_groups != 1) return false;
+    if (vc::opt(vc::OPT_PROJ256) == 0 || d->dtype != VC_BF16 || d->mode != VC_GEMM_PLAIN || d->n_groups != 1) return false;
     const vc_gemm_group& g = d->groups[0];
     if (d->N != 256 || d->Cin % 64 || d->M < 1024 || g.taps < 2 || g.taps > 32 || g.taps * d->Cin < 4096) return false;
     if (d->d_pro_scale || d->pro_relu || d->pro_pool || d->d_R || d->out_f32 || d->drop_keep > 0.0f || d->epi_pool) return false;
@@ -1011,8 +1006,7 @@ extern "C" int vc_conv_wgrad(const vc_wgrad_desc* d, void* stream) {
     // The groups arrive sorted by size (the kernel reads a.g[] back to front as "heaviest first").
     bool sorted = d->n_groups >= 8;
     for (int g = 1; g < d->n_groups && sorted; ++g) sorted = d->groups[g].taps >= d->groups[g - 1].taps;
-    const char* env = std::getenv("VC_WGRAD_XCD");
-    if (sorted && !(env && env[0] == '0')) {
+    if (sorted && vc::opt(vc::OPT_WGRAD_XCD) != 0) {
         long per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0}, total = 0;
         for (int gi = 0; gi < d->n_groups; ++gi) {
             const vc_wgrad_group& gg = d->groups[d->n_groups - 1 - gi];

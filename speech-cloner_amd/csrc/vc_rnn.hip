@@ -648,9 +648,9 @@ int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw,
     // bf16, 16 sequences per workgroup on MFMA: 3.3 us/step but 16x fewer CUs.  A batch that would
     // occupy a quarter of the chip or more with the first form takes the second, which leaves the
     // CUs to the MFMA-bound launches of the other streams (full path: +7.7 % frames/s at 64
-    // windows); small batches keep the low-latency form.  VC_GRU_MFMA=0 / 1 forces either.
-    const char* gm = getenv("VC_GRU_MFMA");
-    const bool use_valu = gm ? (gm[0] != '1') : (n_seq < 32);
+    // windows); small batches keep the low-latency form.  vc_set_option("gru_mfma", 0 / 1) forces either.
+    const int gm = vc::opt(vc::OPT_GRU_MFMA);
+    const bool use_valu = gm >= 0 ? (gm != 1) : (n_seq < 32);
     if (w_dtype == VC_BF16 && H == 256) return use_valu ? launch_resident<256, __bf16, 512>(a, d_workspace, workspace_bytes, st)
                                                         : launch_mfma<256>(a, d_workspace, workspace_bytes, st);
     if (w_dtype == VC_BF16 && H == 128) return use_valu ? launch_resident<128, __bf16, 256>(a, d_workspace, workspace_bytes, st)

@@ -32,6 +32,7 @@ class decoder_specs:
 
         self.encoder = encoder
         self._create_tf_session()
+        modules.apply_options(cfg_d.get('kernel_options'))
         self._build_model(reuse=None)
 
         self.opt_state = {'dec_opt/learning_rate': np.float32(cfg_d.get('learning_rate', 1e-3)),

@@ -49,6 +49,7 @@ class encoder_spec_phn:
             cfg_d.get('compute_dtype', 'float32'),
             device=cfg_d.get('device', 'cuda'))
         self.sess = self.store                       # shared with a decoder, like the TF session
+        modules.apply_options(cfg_d.get('kernel_options'))
 
         self._build_model(input_shape=self.cfg_d['input_shape'],
                           n_output=self.cfg_d['n_output'],

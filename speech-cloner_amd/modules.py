@@ -17,7 +17,6 @@ and cached; ``VariableStore.invalidate()`` drops them after a weight update.
 ``use_lstm`` true, which no shipped configuration sets -> ``CBHG(use_lstm=True)`` raises.
 """
 import contextlib
-import os
 import ctypes as C
 import math
 import threading
@@ -25,6 +24,23 @@ import threading
 import numpy as np
 
 import _vc
+
+# Host-side fusion choices (one launch vs several for the same arithmetic).  Not read from the environment: set them
+# here (modules.OPTIONS['prenet_chain'] = False) or per model through the optional config key 'kernel_options'.
+# Kernel selectors inside the library are _vc.set_option / vc_set_option (include/vc_hip.h).
+OPTIONS = {'prenet_chain': True,      # both prenet layers in one launch (vc_prenet_chain)
+           'highway_chain': True,     # all highway layers + the GRU input projection in one launch (vc_highway_chain)
+           'cbhg_front': True}        # the encoder's whole pre-recurrence chain in one launch (vc_cbhg_front)
+
+
+def apply_options(d):
+    """Optional config key 'kernel_options' of encoder_spec_phn / decoder_specs: {name: value} with names from
+    OPTIONS (bool) or vc_set_option (int).  Process-global, like the library's own table."""
+    for k, v in (d or {}).items():
+        if k in OPTIONS:
+            OPTIONS[k] = bool(v)
+        else:
+            _vc.set_option(k, int(v))
 
 BN_EPS = 1e-3           # tf.contrib.layers.batch_norm epsilon (read from the reference's .meta)
 BN_DECAY = 0.999        # moving-average decay
@@ -466,7 +482,7 @@ def prenet(inputs, num_units=None, embed_size=256, dropout_rate=0.5, is_training
     x = _as3(inputs)
     N_, T_, Cx = x.shape
     if (not is_training and store.dtype == torch.bfloat16 and x.dtype in (torch.bfloat16, torch.float32)
-            and os.environ.get('VC_PRENET_CHAIN', '1') != '0'
+            and OPTIONS['prenet_chain']
             and _vc.lib().vc_prenet_chain_supported(Cx, num_units[0], num_units[1])):
         # both layers in one launch, the intermediate never leaves the registers (vc_prenet_chain)
         with variable_scope(scope):
@@ -523,7 +539,7 @@ def highway_chain(inputs, num_units, n_layers, scope_fmt='highwaynet_{}', gru_sc
     x = _as3(inputs)
     N_, T_, Cx = x.shape
     fused = (store.dtype == torch.bfloat16 and Cx == num_units and Cx in (128, 256) and N_ * T_ >= 128
-             and 1 <= n_layers <= 8 and os.environ.get('VC_HIGHWAY_CHAIN', '1') != '0')
+             and 1 <= n_layers <= 8 and OPTIONS['highway_chain'])
     if not fused:
         out = x
         for i in range(n_layers):
@@ -655,7 +671,7 @@ def prenet_CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks
     decoder.py:100-125 / 134-153 call them.  The shipped encoder shape in bf16 runs everything up to the
     recurrence as ONE launch (vc_cbhg_front: the layers are 40 channels wide, launch- and HBM-latency
     bound one by one); every other shape is prenet() + CBHG().  ``inputs`` may be float32 there (the
-    conversion is part of the launch).  VC_CBHG_FRONT=0 switches the fused form off (A/B)."""
+    conversion is part of the launch).  OPTIONS['cbhg_front'] = False switches the fused form off (A/B)."""
     torch = _torch()
     store = _store()
     x = _as3(inputs)
@@ -663,7 +679,7 @@ def prenet_CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks
     cin = Cx if in_features is None else in_features
     E = embed_size
     fused = (not is_training and not use_lstm and store.dtype == torch.bfloat16 and cin == Cx
-             and os.environ.get('VC_CBHG_FRONT', '1') != '0'
+             and OPTIONS['cbhg_front']
              and bool(_vc.lib().vc_cbhg_front_supported(Cx, E, E // 2, num_conv_banks, 128, num_highwaynet_blocks, E // 2, T_)))
     if not fused:
         pre = prenet(convert(x, store.dtype), None, E, dropout_rate, is_training, scope=prenet_scope, in_features=in_features)

@@ -70,3 +70,30 @@ def test_fused_launch_shape_queries_and_validation_without_gpu():
     rc = lib.vc_mfma_pack(None, 32, 16, 16, 0, None, None)
     assert rc != 0 and b'vc_mfma_pack' in lib.vc_last_error()
     assert ctypes.sizeof(_vc.CbhgFrontDesc) % 8 == 0
+
+
+def test_kernel_options_are_explicit_and_ablations_are_not_shipped():
+    """Kernel selection goes through vc_set_option only: the library does not import getenv, unknown names are
+    errors, and the result-corrupting ablation switches are rejected by the shipped (non -DVC_ABLATE) build."""
+    import subprocess
+    import _vc
+    lib = _vc.lib()
+    assert lib.vc_ablate_build() == 0
+    assert _vc.get_option('gru_mfma') == -1
+    _vc.set_option('gru_mfma', 1)
+    assert _vc.get_option('gru_mfma') == 1
+    with _vc.options(gru_mfma=0, bank256=0):
+        assert _vc.get_option('gru_mfma') == 0 and _vc.get_option('bank256') == 0
+    assert _vc.get_option('gru_mfma') == 1 and _vc.get_option('bank256') == -1
+    _vc.set_option('gru_mfma', -1)
+    with pytest.raises(_vc.VCError, match='unknown option'):
+        _vc.set_option('no_such_switch', 1)
+    for name in ('ablate_bank256', 'ablate_bank256_only', 'ablate_cbhg_front'):
+        with pytest.raises(_vc.VCError, match='VC_ABLATE'):
+            _vc.set_option(name, 1)
+    und = subprocess.run(['nm', '-D', '--undefined-only', _vc.LIB_PATH], capture_output=True, text=True).stdout
+    assert 'getenv' not in und
+    import modules
+    src = open(os.path.join(ROOT, 'speech-cloner_amd', 'modules.py')).read() + open(os.path.join(ROOT, 'speech-cloner_amd', '_vc.py')).read()
+    assert 'os.environ[' not in src and 'environ.setdefault' not in src      # the package never writes the environment
+    assert set(modules.OPTIONS) == {'prenet_chain', 'highway_chain', 'cbhg_front'}

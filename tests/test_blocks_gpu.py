@@ -8,9 +8,26 @@ import numpy as np
 import pytest
 import torch
 
+import _vc
+
 from oracle import model_oracle as mo
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _default_kernel_options():
+    """Tests switch between equivalent kernels with _vc.set_option / modules.OPTIONS (never the environment);
+    every test starts from, and leaves, the library's defaults."""
+    import _vc
+    import modules
+    names = ('bank256', 'bank256_xcd', 'conv256', 'conv256_min_k', 'conv256_wm', 'proj256', 'wgrad_xcd', 'gru_mfma',
+             'cbhg_front_mi')
+    saved = dict(modules.OPTIONS)
+    yield
+    for n in names:
+        _vc.set_option(n, -1)
+    modules.OPTIONS.update(saved)
 
 
 def _store(dtype, wdict=None):
@@ -117,7 +134,7 @@ def test_conv1d_banks(dtype, K, cin):
                                                          (11, 197, 256, 128, 7, 0, True),
                                                          # one tap per slab (dense layers): the slab is needed one section after its request
                                                          (7, 400, 2048, 128, 1, 0, False), (2, 400, 1024, 256, 1, 0, True), (1, 130, 4096, 128, 1, 0, False)])
-def test_conv1d_deep_pipeline_kernel(N, T, cin, f, size, pool, with_res, monkeypatch):
+def test_conv1d_deep_pipeline_kernel(N, T, cin, f, size, pool, with_res):
     """Long-K single-filter bf16 convolutions run on vc_conv256.hip (LDS-direct operand loads, the
     max-pool taken on the fragments).  Bit-identical to conv_kernel / gemm_kernel and within the bf16
     tolerance of the oracle; window edges (SAME padding, last frame pooling with itself) included."""
@@ -135,9 +152,9 @@ def test_conv1d_deep_pipeline_kernel(N, T, cin, f, size, pool, with_res, monkeyp
             v = rng.uniform(0.5, 1.5, f) if nm in ('gamma', 'moving_variance') else rng.uniform(-0.3, 0.3, f)
             st.assign('c/p1/' + nm, v.astype(np.float32))
         kw = dict(filters=f, size=size, scope='p1', bn_scope='p1', activation_fn='relu', pool_input=pool, residual=rd)
-        monkeypatch.setenv('VC_CONV256', '0')
+        _vc.set_option('conv256', 0)
         y_old = modules.conv1d(xd, **kw)
-        monkeypatch.setenv('VC_CONV256', '1')
+        _vc.set_option('conv256', -1)
         poison_gpu_state()
         y = modules.conv1d(xd, **kw)
         again = [modules.conv1d(xd, **kw) for _ in range(12)]             # a rare ordering bug shows as a rare mismatch
@@ -155,7 +172,7 @@ def test_conv1d_deep_pipeline_kernel(N, T, cin, f, size, pool, with_res, monkeyp
 
 
 @pytest.mark.parametrize('N,T,cin,K', [(3, 100, 128, 32), (5, 333, 64, 8), (2, 400, 256, 32), (1, 256, 64, 2)])
-def test_conv1d_banks_paired_256_tile_kernel(N, T, cin, K, monkeypatch):
+def test_conv1d_banks_paired_256_tile_kernel(N, T, cin, K):
     """bf16 banks with >= 256 frames, 64-channel slabs and an even K run on vc_bank256.hip (filter
     widths paired, 256 x 256 tiles).  Checked against the oracle at the bf16 tolerance and, bit for
     bit, against conv_kernel (same products in the same order), with LDS left full of NaN by the
@@ -171,9 +188,9 @@ def test_conv1d_banks_paired_256_tile_kernel(N, T, cin, K, monkeypatch):
         for nm in ('beta', 'gamma', 'moving_mean', 'moving_variance'):
             v = rng.uniform(0.5, 1.5, 128 * K) if nm in ('gamma', 'moving_variance') else rng.uniform(-0.3, 0.3, 128 * K)
             st.assign('e/conv1d_banks/bn/' + nm, v.astype(np.float32))
-        monkeypatch.setenv('VC_BANK256', '0')
+        _vc.set_option('bank256', 0)
         y_old = modules.conv1d_banks(xd, K=K, is_training=False)
-        monkeypatch.setenv('VC_BANK256', '1')
+        _vc.set_option('bank256', -1)
         nan = torch.full((4096, 2048), float('nan'), device='cuda')
         out = torch.empty(2048, device='cuda')
         ys = []
@@ -260,7 +277,7 @@ def test_epi_pool_is_rejected_where_unsupported():
 
 
 @pytest.mark.parametrize('N,T,H,L', [(2, 400, 256, 6), (3, 100, 128, 4), (5, 77, 256, 3), (1, 128, 128, 1), (2, 333, 256, 8)])
-def test_highway_chain_single_launch(N, T, H, L, monkeypatch):
+def test_highway_chain_single_launch(N, T, H, L):
     """All highwaynet layers of a CBHG block in one launch (activations stay in LDS between layers):
     bit-identical to the per-layer launches, layer by layer within the bf16 tolerance of the oracle."""
     import modules
@@ -270,14 +287,14 @@ def test_highway_chain_single_launch(N, T, H, L, monkeypatch):
     x = torch.from_numpy(rng.standard_normal((N, T, H)).astype(np.float32))
     xd = modules.convert(x.cuda(), st.dtype)
     with modules.variable_store(st), modules.variable_scope('h'):
-        monkeypatch.setenv('VC_HIGHWAY_CHAIN', '0')
+        modules.OPTIONS['highway_chain'] = False
         modules.highway_chain(xd, H, L)
         for i in range(L):
             st.assign('h/highwaynet_%d/dense1/bias' % i, rng.uniform(-0.2, 0.2, H).astype(np.float32))
             st.assign('h/highwaynet_%d/dense2/bias' % i, rng.uniform(-1.2, 0.2, H).astype(np.float32))
         y_ref = modules.highway_chain(xd, H, L)
         g_ref = modules.highway_chain(xd, H, L, gru_scope='gru')          # per-layer launches + dense + recurrence
-        monkeypatch.setenv('VC_HIGHWAY_CHAIN', '1')
+        modules.OPTIONS['highway_chain'] = True
         poison_gpu_state()
         y = modules.highway_chain(xd, H, L)
         g = modules.highway_chain(xd, H, L, gru_scope='gru')              # the GRU's input projection rides on the chain
@@ -294,7 +311,7 @@ def test_highway_chain_single_launch(N, T, H, L, monkeypatch):
 
 
 @pytest.mark.parametrize('H,T,N', [(128, 60, 3), (256, 40, 35), (256, 24, 16), (128, 50, 33)])
-def test_gru_mfma_recurrence(H, T, N, monkeypatch):
+def test_gru_mfma_recurrence(H, T, N):
     """The 16-sequences-per-workgroup MFMA recurrence (chosen by itself from 32 sequences up, forced
     here) against the oracle, incl. partly filled sequence groups, and run-to-run identical."""
     import modules
@@ -302,11 +319,11 @@ def test_gru_mfma_recurrence(H, T, N, monkeypatch):
     st = _store('bfloat16')
     x = torch.from_numpy((0.7 * rng.standard_normal((N, T, H))).astype(np.float32))
     xd = modules.convert(x.cuda(), st.dtype)
-    monkeypatch.setenv('VC_GRU_MFMA', '1')
+    _vc.set_option('gru_mfma', 1)
     with modules.variable_store(st), modules.variable_scope('g'):
         y = modules.gru(xd, num_units=H, bidirection=True)
         y2 = modules.gru(xd, num_units=H, bidirection=True)
-        monkeypatch.setenv('VC_GRU_MFMA', '0')
+        _vc.set_option('gru_mfma', 0)
         yv = modules.gru(xd, num_units=H, bidirection=True)
     assert torch.equal(y, y2)
     cast = lambda t: t.float().bfloat16().double()
@@ -345,7 +362,7 @@ def test_gemm_argument_errors_are_reported():
 
 @pytest.mark.parametrize('N,T,L,f32_in,mi', [(3, 400, 1, True, '2'), (2, 250, 2, False, '2'), (1, 97, 0, True, '2'),
                                               (5, 400, 1, True, '4'), (2, 123, 3, False, '4'), (1, 8, 1, True, '2')])
-def test_encoder_front_single_launch(N, T, L, f32_in, mi, monkeypatch):
+def test_encoder_front_single_launch(N, T, L, f32_in, mi):
     """prenet + CBHG of the shipped encoder shape as ONE launch up to the recurrence (vc_cbhg_front) against
     the per-layer launches and the oracle: window edges (SAME padding of every convolution, the pool's last
     frame), tiles that do not divide the window, 0..3 highway layers, float32 / bf16 features, both tile
@@ -358,7 +375,7 @@ def test_encoder_front_single_launch(N, T, L, f32_in, mi, monkeypatch):
     xin = x if f32_in else modules.convert(x, st.dtype)
     args = dict(embed_size=80, num_conv_banks=6, num_highwaynet_blocks=L, dropout_rate=0.4, is_training=False)
     with modules.variable_store(st), modules.variable_scope('e'):
-        monkeypatch.setenv('VC_CBHG_FRONT', '0')
+        modules.OPTIONS['cbhg_front'] = False
         modules.prenet_CBHG(xin, **args)                                   # creates the variables
         for n, v in list(st.vars.items()):                                   # non-trivial norms / biases
             if n.endswith('gamma') or n.endswith('moving_variance'):
@@ -366,8 +383,8 @@ def test_encoder_front_single_launch(N, T, L, f32_in, mi, monkeypatch):
             elif n.endswith('beta') or n.endswith('moving_mean') or n.endswith('bias'):
                 st.assign(n, rng.uniform(-0.3, 0.3, tuple(v.shape)).astype(np.float32))
         y_ref = modules.prenet_CBHG(xin, **args)
-        monkeypatch.setenv('VC_CBHG_FRONT', '1')
-        monkeypatch.setenv('VC_CBHG_FRONT_MI', mi)
+        modules.OPTIONS['cbhg_front'] = True
+        _vc.set_option('cbhg_front_mi', int(mi))
         assert modules._vc.lib().vc_cbhg_front_supported(80, 80, 40, 6, 128, L, 40, T)
         poison_gpu_state()
         y = modules.prenet_CBHG(xin, **args)
@@ -387,7 +404,7 @@ def test_encoder_front_single_launch(N, T, L, f32_in, mi, monkeypatch):
 
 
 @pytest.mark.parametrize('N,T,cin,E', [(2, 400, 61, 256), (3, 77, 80, 512), (1, 1, 61, 256), (64, 400, 80, 512)])
-def test_prenet_single_launch(N, T, cin, E, monkeypatch):
+def test_prenet_single_launch(N, T, cin, E):
     """The decoder stages' prenet as one launch (vc_prenet_chain: intermediate in registers) against the two
     dense launches and the oracle; ragged last block, NaN-poisoned LDS."""
     import modules
@@ -399,13 +416,13 @@ def test_prenet_single_launch(N, T, cin, E, monkeypatch):
     x[:, :, :cin] = 0.7 * rng.standard_normal((N, T, cin))
     xd = modules.convert(torch.from_numpy(x).cuda(), st.dtype)
     with modules.variable_store(st), modules.variable_scope('p'):
-        monkeypatch.setenv('VC_PRENET_CHAIN', '0')
+        modules.OPTIONS['prenet_chain'] = False
         modules.prenet(xd, None, E, 0.1, False, in_features=cin)
         for n, v in list(st.vars.items()):
             if n.endswith('bias'):
                 st.assign(n, rng.uniform(-0.3, 0.3, tuple(v.shape)).astype(np.float32))
         y_ref = modules.prenet(xd, None, E, 0.1, False, in_features=cin)
-        monkeypatch.setenv('VC_PRENET_CHAIN', '1')
+        modules.OPTIONS['prenet_chain'] = True
         assert modules._vc.lib().vc_prenet_chain_supported(cp, E, E // 2)
         poison_gpu_state()
         y = modules.prenet(xd, None, E, 0.1, False, in_features=cin)
@@ -421,10 +438,10 @@ def test_prenet_single_launch(N, T, cin, E, monkeypatch):
 
 
 @pytest.mark.parametrize('N,T,cin,k', [(4, 400, 4096, 3), (5, 250, 1024, 5), (3, 400, 2048, 2)])
-def test_wide_projection_on_the_bank_tiles(N, T, cin, k, monkeypatch):
+def test_wide_projection_on_the_bank_tiles(N, T, cin, k):
     """A single 256-channel convolution with a long K (decoder stage 2's first k = 3 projection) runs on the bank
-    kernel's 256 x 256 tiles (its halves as a pair of EQUAL width): bit-identical to conv256_kernel / conv_kernel,
-    window edges and a ragged last tile included, NaN-poisoned LDS."""
+    kernel's 256 x 256 tiles (its halves as a pair of EQUAL width): bit-identical to conv256_kernel / conv_kernel
+    and within the bf16 tolerance of the oracle; window edges and a ragged last tile included, NaN-poisoned LDS."""
     import modules
     from conftest import poison_gpu_state
     rng = np.random.RandomState(cin + k)
@@ -432,7 +449,7 @@ def test_wide_projection_on_the_bank_tiles(N, T, cin, k, monkeypatch):
     x = torch.from_numpy(rng.standard_normal((N, T, cin)).astype(np.float32) * 0.5)
     xd = modules.convert(x.cuda(), st.dtype)
     with modules.variable_store(st), modules.variable_scope('p'):
-        monkeypatch.setenv('VC_PROJ256', '0')
+        _vc.set_option('proj256', 0)
         kw = dict(filters=256, size=k, scope='c', bn_scope='c', activation_fn='relu')
         modules.conv1d(xd, **kw)
         for n, v in list(st.vars.items()):
@@ -441,12 +458,17 @@ def test_wide_projection_on_the_bank_tiles(N, T, cin, k, monkeypatch):
             elif n.endswith('beta') or n.endswith('moving_mean'):
                 st.assign(n, rng.uniform(-0.3, 0.3, tuple(v.shape)).astype(np.float32))
         y_ref = modules.conv1d(xd, **kw)
-        monkeypatch.setenv('VC_PROJ256', '1')
+        _vc.set_option('proj256', -1)
         poison_gpu_state()
         y = modules.conv1d(xd, **kw)
     torch.cuda.synchronize()
     assert not torch.isnan(y.float()).any()
     assert torch.equal(y, y_ref)
+    # and against the oracle (modules.py:334-335: conv1d k, SAME, no bias -> bn -> relu) on the bf16-rounded operands
+    w = {n: v.cpu().double() for n, v in st.vars.items()}
+    cast = lambda t: t.bfloat16().double()
+    ref = torch.relu(mo.bn(mo.conv1d(cast(x), cast(st.vars['p/c/conv1d/kernel'].cpu())), w, 'p/c'))
+    _close(y, ref, TOL['bfloat16'], 'proj256 cin=%d k=%d' % (cin, k))
 
 
 def test_softmax_dual_output_equals_two_launches():

@@ -1,11 +1,13 @@
 """A/B of run-time switches INSIDE the three-stream step, on one box, interleaved (ABAB...) so that box and
 clock drift cancel: every configuration runs `rounds` times `steps` steps; mean and spread of ms/step.
-  python tools/ab_step.py "VC_PRENET_CHAIN=0" "VC_BANK256_XCD=1" ...      (the default is always included)"""
+  python tools/ab_step.py "prenet_chain=0" "bank256_xcd=1" ...      (the default is always included)
+Switch names: modules.OPTIONS keys (prenet_chain, highway_chain, cbhg_front) and vc_set_option names (include/vc_hip.h)."""
 import os, sys, time, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'speech-cloner_amd')):
     sys.path.insert(0, p)
-import torch, bench, audio_lib
+import torch, bench, audio_lib, modules, _vc
+DEFAULTS = dict(modules.OPTIONS)
 cfgs = [''] + sys.argv[1:]
 keys = sorted({kv.split('=')[0] for c in cfgs for kv in c.split(',') if kv})
 NS, steps, rounds = 10, 60, 6
@@ -29,14 +31,17 @@ def step():
             ev = torch.cuda.Event(); ev.record(st_); main.wait_event(ev)
             dec.forward(xi)
 def apply(c):
-    for k in keys: os.environ.pop(k, None)
+    modules.OPTIONS.update(DEFAULTS)
+    for k in keys:
+        if k not in DEFAULTS and k not in ('STREAMS', 'CHUNK'): _vc.set_option(k, -1)
     ns[0] = NS; chunk[0] = 64
     for kv in c.split(','):
         if kv:
             k, v = kv.split('=')
             if k == 'STREAMS': ns[0] = int(v)              # pseudo-switch: number of streams the steps rotate over
             elif k == 'CHUNK': chunk[0] = int(v)           # pseudo-switch: windows per launch (64 = one chunk per step)
-            else: os.environ[k] = v
+            elif k in DEFAULTS: modules.OPTIONS[k] = v != '0'
+            else: _vc.set_option(k, int(v))
 res = {c: [] for c in cfgs}
 for c in cfgs:                                   # build every cache first
     apply(c)

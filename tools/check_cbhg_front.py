@@ -1,10 +1,10 @@
 """A/B of the encoder's fused pre-recurrence launch (vc_cbhg_front) against the per-layer launches
-(VC_CBHG_FRONT=0): largest differences of the GRU output / logits / posteriors, and both timings."""
+(modules.OPTIONS["cbhg_front"] = False): largest differences of the GRU output / logits / posteriors, and both timings."""
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'speech-cloner_amd')):
     sys.path.insert(0, p)
-import numpy as np, torch, bench
+import numpy as np, torch, bench, modules
 from encoder import encoder_spec_phn
 g = np.load(os.path.join(ROOT, 'tests', 'golden', 'encoder_fwd.npz'))
 cfg = json.load(open(os.path.join(ROOT, 'speech-cloner_amd', 'hp', 'encoder_cfg_d.json')))
@@ -14,12 +14,12 @@ x3 = torch.from_numpy(g['x']).cuda()
 x = torch.cat([x3] * 22, 0)[:64].contiguous()
 outs = {}
 for mode in ('0', '1'):
-    os.environ['VC_CBHG_FRONT'] = mode
+    modules.OPTIONS['cbhg_front'] = mode == '1'
     o = enc.forward(x)
     torch.cuda.synchronize()
     outs[mode] = {k: v.float().cpu() for k, v in o.items() if k in ('CBHG_out', 'y_logits', 'y_pred')}
     ms = bench.time_events(lambda: enc.forward(x), 20)
-    print('VC_CBHG_FRONT=%s  encoder forward %.3f ms' % (mode, ms))
+    print('cbhg_front=%s  encoder forward %.3f ms' % (mode, ms))
 for k in outs['0']:
     d = (outs['0'][k] - outs['1'][k]).abs()
     print('%-9s max |fused - layers| = %.4g  mean %.3g  (ref max %.3g)  nan: %s' % (k, d.max(), d.mean(), outs['0'][k].abs().max(), bool(torch.isnan(outs['1'][k]).any())))
