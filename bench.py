@@ -3,6 +3,12 @@
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload full|frontend|train|vocoder]
 
+Launch forms.  (1) Under torch.distributed.run (RANK / WORLD_SIZE in the environment): this process is one rank.
+(2) Plain `python bench.py --gpus N` with N > 1: this process makes NO GPU call; it starts
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, relays rank 0's JSON line and exits
+with the child's status.  Either way n_gpus is the number of ranks that actually joined the process group, and the
+run fails if that differs from --gpus.
+
 A "step" is one pass of the hot path over one synthetic batch that is already resident in
 HBM.  Multi-GPU: one process per GPU (torch.distributed.run), the utterance batch is sharded
 one full batch per rank with NO data-path collective (inference shards by utterance: SURVEY.md
@@ -68,10 +74,12 @@ def synth_audio(B, L, seed):
 
 def _pmc_traffic(kernel):
     """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01/pmc_summary.json)."""
-    try:
-        return json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_summary.json')))[kernel]['traffic_bytes_per_launch']
-    except Exception:
-        return None
+    for rnd in ('r02', 'r01'):
+        try:
+            return json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_summary.json')))[kernel]['traffic_bytes_per_launch']
+        except Exception:
+            continue
+    return None
 
 
 def time_events(fn, iters):
@@ -159,6 +167,87 @@ MFMA_BF16_PEAK_TF = 2500.0           # MI355X_MICROARCH.md: dense bf16
 MFMA_F32_PEAK_TF = 157.3
 
 
+class _Pipeline:
+    """The bench's step: front-end on the resident batch -> 64 windows -> encode + decode, consecutive steps rotating
+    over `n_streams` HIP streams (independent batches: one step's latency-bound recurrences run under another step's
+    MFMA-bound filter banks; everything is joined by the synchronize() that closes a timed region)."""
+
+    def __init__(self, wav, dec, window_batch, n_streams):
+        import audio_lib
+        self.audio_lib, self.wav, self.dec, self.wb = audio_lib, wav, dec, window_batch
+        self.streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else None
+        self.n_streams = n_streams
+        self.chunk_no = 0
+        self.fe_out = None
+        self.res = {}
+        self.nwin = wav.shape[0] * 2
+
+    def windows(self):
+        return self.fe_out[0][:, :800, :].reshape(self.nwin, 400, 80)
+
+    def step(self):
+        self.fe_out = self.audio_lib.calc_MFCC_input_batch(self.wav, None, out=self.fe_out, **FE_KW)
+        x = self.windows()
+        if self.streams is None:
+            for i in range(0, self.nwin, self.wb):
+                o = self.dec.forward(x[i:i + self.wb].contiguous())
+                self.res[i] = (o['y_mel'], o['y_stft'], o['y_phn'])
+            return
+        main = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(main)
+        for i in range(0, self.nwin, self.wb):
+            st_ = self.streams[self.chunk_no % len(self.streams)]
+            self.chunk_no += 1
+            st_.wait_event(ready)
+            with torch.cuda.stream(st_):
+                xi = x[i:i + self.wb].contiguous()
+                xi.record_stream(st_)
+                copied = torch.cuda.Event()
+                copied.record(st_)
+                main.wait_event(copied)                # the next step's front-end overwrites fe_out
+                o = self.dec.forward(xi)
+                self.res[(i, self.chunk_no % (2 * len(self.streams)))] = (o['y_mel'], o['y_stft'], o['y_phn'])
+
+    def setup(self):
+        # like loading the model: every stream's allocator pool and every weight-layout cache is built once
+        for _ in range(2 * self.n_streams if self.streams else 1):
+            self.step()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, world):
+        for _ in range(warmup):
+            self.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        return time.perf_counter() - t0
+
+
+def _rocprof_bank_avg():
+    """Average duration (ms) of the step-2 filter-bank launch in the committed rocprofv3 --kernel-trace --stats run of
+    tools/prof_kernels.py bank (>= 50 calls), profiles/r02/bank_step2_kernel_stats.csv -- reported beside the live
+    HIP-event figure so the line can be checked against profiles/."""
+    import csv
+    for rnd in ('r02', 'r01'):
+        f = os.path.join(ROOT, 'profiles', rnd, 'bank_step2_kernel_stats.csv')
+        try:
+            for r in csv.DictReader(open(f)):
+                if 'bank256_kernel' in r['Name']:
+                    return {'file': 'profiles/%s/bank_step2_kernel_stats.csv' % rnd, 'calls': int(r['Calls']),
+                            'avg_ms': round(float(r['AverageNs']) / 1e6, 4)}
+        except Exception:
+            continue
+    return None
+
+
 def bench_full(args, rank, world):
     """front-end on 32 x 4 s (configs[1] input) -> first 800 frames of every utterance as two
     400-frame windows -> encode + decode, `--window-batch` windows per launch."""
@@ -169,71 +258,23 @@ def bench_full(args, rank, world):
     enc, dec = load_models(args.dtype, rank)
     nwin = B * 2
     frames = nwin * T
-    fe_out = None
-    res = {}
-
-    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
-    chunk_no = [0]
-
-    def step():
-        nonlocal fe_out
-        fe_out = audio_lib.calc_MFCC_input_batch(wav, None, out=fe_out, **FE_KW)
-        x = fe_out[0][:, :2 * T, :].reshape(nwin, T, 80)
-        if streams is None:
-            for i in range(0, nwin, args.window_batch):
-                o = dec.forward(x[i:i + args.window_batch].contiguous())
-                res[i] = (o['y_mel'], o['y_stft'], o['y_phn'])
-            return
-        # independent window chunks on separate HIP streams: one chunk's latency-bound recurrences
-        # (<= 128 workgroups) overlap with another chunk's GEMMs
-        # (consecutive steps are independent batches, so they also alternate streams: step i+1's
-        # front-end and GEMMs run under step i's recurrences; everything is joined by the
-        # synchronize() that closes the timed region)
-        main = torch.cuda.current_stream()
-        ready = torch.cuda.Event()
-        ready.record(main)
-        for i in range(0, nwin, args.window_batch):
-            st_ = streams[chunk_no[0] % len(streams)]
-            chunk_no[0] += 1
-            st_.wait_event(ready)
-            with torch.cuda.stream(st_):
-                xi = x[i:i + args.window_batch].contiguous()
-                xi.record_stream(st_)
-                copied = torch.cuda.Event()
-                copied.record(st_)
-                main.wait_event(copied)                # the next step's front-end overwrites fe_out
-                o = dec.forward(xi)
-                res[(i, chunk_no[0] % (2 * len(streams)))] = (o['y_mel'], o['y_stft'], o['y_phn'])
-
-    # setup, like loading the model: every stream's allocator pool and every weight-layout cache is built once
-    for _ in range(2 * args.streams if streams else 1):
-        step()
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    dt = time.perf_counter() - t0
+    pipe = _Pipeline(wav, dec, args.window_batch, args.streams)
+    pipe.setup()
+    dt = pipe.timed(args.steps, args.warmup, world)
+    fe_out = pipe.fe_out
 
     extra = {}
     if rank == 0:
         # dominant-kernel timings with HIP events on the launch stream
-        x = fe_out[0][:, :2 * T, :].reshape(nwin, T, 80)[:args.window_batch].contiguous()
+        x = pipe.windows()[:args.window_batch].contiguous()
         st = dec.store
         W = args.window_batch
         peak = MFMA_BF16_PEAK_TF if args.dtype == 'bfloat16' else MFMA_F32_PEAK_TF
+        NL = 50                                          # launches averaged for the roofline line
         with modules.variable_store(st), modules.variable_scope('decoder'), modules.variable_scope('step2'), \
                 modules.variable_scope('CBHG'):
             pre = torch.randn(W, T, 256, device='cuda').to(st.dtype)
-            ms_bank = time_events(lambda: modules.conv1d_banks(pre, K=32, is_training=False), 20)
+            ms_bank = time_events(lambda: modules.conv1d_banks(pre, K=32, is_training=False), NL)
             bank = modules.conv1d_banks(pre, K=32, is_training=False)
             ms_p1 = time_events(lambda: modules.conv1d(bank, filters=256, size=3, scope="conv1d_1", bn_scope="conv1d_1",
                                                        activation_fn='relu', pool_input=2), 20)
@@ -245,19 +286,29 @@ def bench_full(args, rank, world):
         ms_all = time_events(lambda: dec.forward(x), 5)
         ach = fl_bank / (ms_bank * 1e-3) / 1e12
         # HBM-side bytes per launch of this kernel from the committed rocprofv3 --pmc passes
-        # (profiles/r01/pmc_summary.json: (2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 correction)
+        # ((2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 correction of MI355X_MICROARCH.md)
         traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'r01', 'pmc_summary.json')))
-            if args.dtype == 'bfloat16' and W == 64:
-                traffic = pm['bank256_kernel_bf16_step2']['traffic_bytes_per_launch']
-        except Exception:
-            traffic = None
+        if args.dtype == 'bfloat16' and W == 64:
+            for rnd in ('r02', 'r01'):
+                try:
+                    pm = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_summary.json')))
+                    traffic = pm['bank256_kernel_bf16_step2']['traffic_bytes_per_launch']
+                    break
+                except Exception:
+                    continue
         kname = 'bank256_kernel' if args.dtype == 'bfloat16' else 'conv_kernel<float32>'
         extra['roofline'] = {'kernel': '%s (decoder step2 conv1d_banks, 32 filter widths)' % kname,
                              'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s',
                              'frac': round(ach / peak, 4), 'traffic': traffic,
-                             'algorithmic_flop_per_launch': fl_bank, 'avg_kernel_ms': round(ms_bank, 4)}
+                             'algorithmic_flop_per_launch': fl_bank, 'avg_kernel_ms': round(ms_bank, 4),
+                             'timing': 'HIP events on the launch stream, average of %d back-to-back launches on this box '
+                                       '(the quantity frac is computed from); rocprof_committed = the same launch under '
+                                       'rocprofv3 --kernel-trace --stats on the box that produced profiles/' % NL,
+                             'rocprof_committed': _rocprof_bank_avg() if (args.dtype == 'bfloat16' and W == 64) else None}
+        one = (ms_fe + ms_all * (nwin / W)) * 1e-3
+        extra['single_stream'] = {'value': round(frames / one, 1), 'unit': 'frames/s', 'ms_per_step': round(one * 1e3, 4),
+                                  'what': 'latency-bound caller: one batch at a time on one stream (front-end + encode + '
+                                          'decode of %d windows, HIP events, no overlap between batches)' % nwin}
         extra['stages'] = {
             'frontend_ms': round(ms_fe, 4), 'frontend_frames_per_s': round(B * (1 + L // 80) / (ms_fe * 1e-3), 1),
             'frontend_GBps_vs_8TBps': round(FE_BYTES_PER_FRAME * B * (1 + L // 80) / (ms_fe * 1e-3) / 1e9, 1),
@@ -267,6 +318,21 @@ def bench_full(args, rank, world):
             'dec2_proj1_ms': round(ms_p1, 4), 'dec2_proj1_TFLOPs': round(fl_p1 / (ms_p1 * 1e-3) / 1e12, 2),
             'dec2_gru_ms': round(ms_gru, 4), 'dec2_gru_us_per_step': round(ms_gru * 1e3 / T, 3),
             'model_TFLOPs_end_to_end': round((ENC_FLOP_PER_FRAME + DEC_FLOP_PER_FRAME) * W * T / (ms_all * 1e-3) / 1e12, 2)}
+    # the reference's own precision (float32 arithmetic end to end, exact-f32 MFMA), same workload and pipeline, in the
+    # same driver-observed line; every rank runs it so that ranks stay in step, rank 0 reports its own figure
+    if args.dtype == 'bfloat16' and not args.no_f32:
+        del pipe
+        torch.cuda.empty_cache()
+        enc32, dec32 = load_models('float32', rank)
+        pipe32 = _Pipeline(wav, dec32, args.window_batch, min(args.streams, 4))
+        pipe32.setup()
+        k32 = max(3, min(args.steps, 10))
+        dt32 = pipe32.timed(k32, 1, 1)
+        if rank == 0:
+            extra['f32'] = {'value': round(frames / (dt32 / k32), 1), 'unit': 'frames/s per GPU', 'ms_per_step': round(dt32 / k32 * 1e3, 4),
+                            'steps': k32, 'what': 'same step with float32 weights / activations / accumulation (the '
+                                                  "reference's arithmetic type), %d streams" % min(args.streams, 4)}
+        del pipe32, enc32, dec32
     cfg = {'workload': 'full: STFT+mel front-end on batch 32 x 4 s @ 16 kHz (configs[1] input) -> 64 windows of 400 '
                        'frames -> encoder (enc_14 weights) + decoder (hp/decoder_cfg_d.json sizes, random init), '
                        '%d windows per launch, independent steps pipelined over %d HIP streams' % (args.window_batch, args.streams),
@@ -311,8 +377,40 @@ def bench_train(args, rank, world):
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
+    tr = dec._trainer
+    # the one exchange step of the path, alone: all-reduce of the flat gradient arena (every rank takes part)
+    ar_ms = None
+    if world > 1:
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            torch.distributed.all_reduce(tr.grad, op=torch.distributed.ReduceOp.SUM)
+        e1.record()
+        torch.cuda.synchronize()
+        ar_ms = e0.elapsed_time(e1) / 5
     extra = {'stages': {'last_loss': float(last[2]), 'global_step': int(last[3]),
-                        'params': int(dec._trainer.total), 'allreduce_MB': round(dec._trainer.total * 4 / 1e6, 1)}}
+                        'params': int(tr.total), 'allreduce_MB': round(tr.total * 4 / 1e6, 1),
+                        'allreduce_ms': None if ar_ms is None else round(ar_ms, 4),
+                        'allreduce_busbw_GBps': None if ar_ms is None else
+                        round(2.0 * (world - 1) / world * tr.total * 4 / (ar_ms * 1e-3) / 1e9, 1)}}
+    if rank == 0:
+        import modules
+        # dominant kernel of the step: conv_kernel<float> on the step-2 filter bank (forward; the data- and
+        # weight-gradient launches of the same layer do the same FLOPs), HIP events over 20 launches
+        with modules.variable_store(dec.store), modules.variable_scope('decoder'), modules.variable_scope('step2'), \
+                modules.variable_scope('CBHG'):
+            pre = torch.randn(B, T, 256, device='cuda')
+            ms_bank = time_events(lambda: modules.conv1d_banks(pre, K=32, is_training=False), 20)
+        fl_bank = 2.0 * 256 * 128 * 528 * B * T
+        ach = fl_bank / (ms_bank * 1e-3) / 1e12
+        extra['roofline'] = {'kernel': 'conv_kernel<float> (decoder step2 conv1d_banks forward, exact-f32 MFMA)', 'bound': 'mfma',
+                             'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
+                             'frac': round(ach / MFMA_F32_PEAK_TF, 4), 'traffic': None,
+                             'algorithmic_flop_per_launch': fl_bank, 'avg_kernel_ms': round(ms_bank, 4),
+                             'timing': 'HIP events on the launch stream, average of 20 back-to-back launches'}
+        extra['stages']['step_TFLOPs_at_3x_forward'] = round(3 * DEC_FLOP_PER_FRAME * B * T / (dt / args.steps) / 1e12, 1)
     cfg = {'workload': 'train: decoder fwd+bwd+Adam (float32) on 32 windows x 400 frames per GPU, encoder frozen '
                        '(BASELINE configs[4])', 'global_batch': B * world, 'frames_per_step_per_gpu': B * T}
     return B * T, dt, extra, cfg
@@ -378,9 +476,30 @@ def cpu_baseline_vocoder():
                       'oracle/vocoder_oracle.py (numpy restatement of librosa.istft/stft; single thread)'}
 
 
+def _host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))                         # the GPU box gives one GPU a 16-core share
+
+
+def _median_time(fn, warmups=2, passes=5):
+    """median of >= 5 passes after 2 warm-ups."""
+    for _ in range(warmups):
+        fn()
+    ts = []
+    for _ in range(passes):
+        t0 = time.perf_counter()
+        fn()
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return ts[len(ts) // 2], ts
+
+
 def cpu_baseline_full():
     """Oracle timed on the host: front-end on 2 utterances (numpy) + encode/decode of 2 windows with
-    torch-CPU float32 ops at the shipped sizes (all host threads)."""
+    torch-CPU float32 ops at the shipped sizes (all host threads); 2 warm-ups, median of 5 passes."""
     from oracle import frontend_oracle as fo
     from oracle import model_oracle as mo
     import contextlib
@@ -395,84 +514,192 @@ def cpu_baseline_full():
     we = mo.to_torch({k: v for k, v in w.items() if k.startswith('encoder/')})
     wd = mo.to_torch(mo.init_weights(dec_cfg, 'decoder', seed=2))
     wav = synth_audio(2, 64000, seed=0).numpy()
-    try:
-        ncores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncores = os.cpu_count() or 1
-    ncores = max(1, min(ncores, 16))                 # the GPU box gives one GPU a 16-core share
+    ncores = _host_threads()
     torch.set_num_threads(ncores)
-    t0 = time.perf_counter()
-    feats = [fo.calc_MFCC_input(wav[b], **FE_KW)[0][:400] for b in range(2)]
-    x = torch.from_numpy(np.stack(feats))
-    with torch.no_grad():
-        _, pr, _, _ = mo.encoder_forward(x, we, enc_cfg)
-        mo.decoder_forward(pr, wd, dec_cfg)
-    dt = time.perf_counter() - t0
+
+    def one_pass():
+        feats = [fo.calc_MFCC_input(wav[b], **FE_KW)[0][:400] for b in range(2)]
+        x = torch.from_numpy(np.stack(feats))
+        with torch.no_grad():
+            _, pr, _, _ = mo.encoder_forward(x, we, enc_cfg)
+            mo.decoder_forward(pr, wd, dec_cfg)
+
+    dt, all_t = _median_time(one_pass)
     return {'value': round(800 / dt, 1), 'unit': 'frames/s', 'cores': ncores, 'kind': 'port',
             'sample': '2 utterances -> 2 windows (800 frames) through oracle/frontend_oracle.py (numpy) and '
-                      'oracle/model_oracle.py (torch-CPU float32, %d threads); one pass, no warm-up' % ncores}
+                      'oracle/model_oracle.py (torch-CPU float32, %d threads): CPU restatement (TF/librosa-equivalent), '
+                      'not TensorFlow; 2 warm-ups, median of 5 passes (min %.3f s, max %.3f s)' % (ncores, all_t[0], all_t[-1])}
+
+
+def cpu_baseline_train():
+    """Oracle training step timed on the host: forward (train mode) + autograd backward of the decoder at the shipped
+    sizes on ONE window of 400 frames, torch-CPU float32, all host threads; 2 warm-ups, median of 5 passes."""
+    from oracle import model_oracle as mo
+    import contextlib
+    import io
+    from aux_func import load_cfg_d
+    hp = os.path.join(ROOT, 'speech-cloner_amd', 'hp')
+    with contextlib.redirect_stdout(io.StringIO()):
+        dec_cfg = load_cfg_d(os.path.join(hp, 'decoder_cfg_d.json'))
+    dec_cfg['dropout_rate'] = 0.0                      # (masks are an input of the oracle; their cost is nil)
+    ncores = _host_threads()
+    torch.set_num_threads(ncores)
+    wd = mo.to_torch(mo.init_weights(dec_cfg, 'decoder', seed=2), torch.float32, requires_grad=True)
+    g = torch.Generator().manual_seed(5)
+    ppg = torch.softmax(torch.randn(1, 400, 61, generator=g), -1)
+    tm, ts = torch.rand(1, 400, 80, generator=g) * 0.8, torch.rand(1, 400, 201, generator=g) * 0.8
+
+    def one_pass():
+        for v in wd.values():
+            v.grad = None
+        ym, ys = mo.decoder_forward(ppg, wd, dec_cfg, is_training=True, masks=None, stats_out={})
+        mo.decoder_loss(ym, ys, tm, ts, dec_cfg)[2].backward()
+
+    dt, all_t = _median_time(one_pass)
+    return {'value': round(400 / dt, 1), 'unit': 'frames/s', 'cores': ncores, 'kind': 'port',
+            'sample': '1 window (400 frames) of the 32: train-mode forward + autograd backward through oracle/model_oracle.py '
+                      '(torch-CPU float32, %d threads; no Adam, no dropout masks); 2 warm-ups, median of 5 passes '
+                      '(min %.2f s, max %.2f s)' % (ncores, all_t[0], all_t[-1])}
 
 
 def cpu_baseline_frontend():
-    """Oracle (numpy/scipy restatement of librosa's path) timed on the host: 8 utterances of the
-    same workload (~2-4 s of CPU work per pass, one warm-up + 2 timed passes)."""
+    """Oracle (numpy/scipy restatement of librosa's path) timed on the host: 4 utterances of the same workload per
+    pass; 2 warm-ups, median of 5 passes, single thread."""
     from oracle import frontend_oracle as fo
-    wav = synth_audio(8, 64000, seed=0).numpy()
-    fo.calc_MFCC_input(wav[0], **FE_KW)
+    wav = synth_audio(4, 64000, seed=0).numpy()
+    n = [0]
+
+    def one_pass():
+        n[0] = sum(fo.calc_MFCC_input(wav[b], **FE_KW)[0].shape[0] for b in range(wav.shape[0]))
+
+    dt, all_t = _median_time(one_pass)
+    return {'value': round(n[0] / dt, 1), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
+            'sample': '4 of the 32 utterances (4 s each) per pass through oracle/frontend_oracle.py (numpy/scipy '
+                      'restatement of librosa 0.6; single thread); 2 warm-ups, median of 5 passes'}
+
+
+def bench_stub(args, rank, world):
+    """Launcher self-test (tests/test_bench_launcher_cpu.py): no GPU, no kernels -- a fixed amount of host arithmetic
+    per step so that the launch / rendezvous / barrier / max-over-ranks / JSON plumbing of --gpus N can run on gloo."""
+    if os.environ.get('BENCH_STUB_FAIL_RANK') == str(rank):       # test hook: a failing rank must fail the launcher
+        raise SystemExit(7)
+    x = torch.ones(256, 256)
+    for _ in range(args.warmup):
+        x = (x @ x) / 256.0
+    dist_util_barrier()
     t0 = time.perf_counter()
-    n = 0
-    for _ in range(2):
-        for b in range(wav.shape[0]):
-            n += fo.calc_MFCC_input(wav[b], **FE_KW)[0].shape[0]
+    for _ in range(args.steps):
+        x = (x @ x) / 256.0
+    dist_util_barrier()
     dt = time.perf_counter() - t0
-    return {'value': round(n / dt, 1), 'unit': 'frames/s', 'cores': 1, 'kind': 'port',
-            'sample': '2 passes over 8 of the 32 utterances (4 s each) through oracle/frontend_oracle.py '
-                      '(numpy/scipy restatement of librosa 0.6; single thread)'}
+    assert float(x[0, 0]) == 1.0
+    return 25600, dt, {}, {'workload': 'stub: launcher self-test on the CPU (no kernels, not a measurement)',
+                           'frames_per_step_per_gpu': 25600}
 
 
-def main():
+def dist_util_barrier():
+    import dist_util
+    dist_util.barrier()
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child process tree.  This
+    process has made no GPU call (importing torch does not initialise HIP) and makes none: it only relays."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('MASTER_ADDR', '127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        out = out.rstrip('\n')
+        if out.startswith('{') and '"metric"' in out:
+            line = out                                  # rank 0's result line: relayed last, exactly once
+        elif out:
+            print(out, file=sys.stderr)
+    rc = proc.wait()
+    if rc != 0:
+        print('bench.py: a rank failed (torch.distributed.run exit status %d)' % rc, file=sys.stderr)
+        return rc if 0 < rc < 256 else 1
+    if line is None:
+        print('bench.py: the ranks exited without a result line', file=sys.stderr)
+        return 1
+    print(line)
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=6)
-    ap.add_argument('--workload', default='full', choices=['full', 'frontend', 'train', 'vocoder'])
+    ap.add_argument('--workload', default='full', choices=['full', 'frontend', 'train', 'vocoder', 'stub'])
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
     ap.add_argument('--window-batch', type=int, default=64)
     ap.add_argument('--streams', type=int, default=10,
                     help='HIP streams the independent window chunks / consecutive steps are pipelined over')
+    ap.add_argument('--backend', default=None, choices=['nccl', 'gloo'],
+                    help='process-group backend (default: nccl = RCCL; the stub workload uses gloo)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    args = ap.parse_args()
+    ap.add_argument('--no-f32', action='store_true', help='skip the float32 side measurement of the full workload')
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        raise SystemExit('bench.py: --gpus must be >= 1')
+
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))              # before ANY GPU call of this process
 
     import dist_util
     rank, local, world = dist_util.env_world()
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs a GPU')
-    torch.cuda.set_device(local)
-    dist_util.init('nccl')
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)' % (args.gpus, world))
+    stub = args.workload == 'stub'
+    if not stub:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs a GPU')
+        torch.cuda.set_device(local)
+    backend = args.backend or ('gloo' if stub else 'nccl')
+    dist_util.init(backend)
+    joined = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+    if joined != args.gpus:
+        raise SystemExit('bench.py: %d ranks joined the process group, --gpus %d' % (joined, args.gpus))
 
     if args.workload == 'frontend':
         frames, dt, extra, cfg = bench_frontend(args, rank, world)
     elif args.workload == 'train':
         frames, dt, extra, cfg = bench_train(args, rank, world)
-        args.no_cpu_baseline = True
     elif args.workload == 'vocoder':
         frames, dt, extra, cfg = bench_vocoder(args, rank, world)
+    elif stub:
+        frames, dt, extra, cfg = bench_stub(args, rank, world)
     else:
         frames, dt, extra, cfg = bench_full(args, rank, world)
 
-    dt = dist_util.max_over_ranks(dt, device='cuda')
+    dt = dist_util.max_over_ranks(dt, device='cpu' if backend == 'gloo' else 'cuda')
     if rank == 0:
-        line = {'metric': 'mel frames/sec', 'value': round(frames * world * args.steps / dt, 1), 'unit': 'frames/s',
-                'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        par = {'train': 'data parallel x%d: one batch per rank, one all-reduce of the flat gradient arena per step' % joined,
+               }.get(args.workload, 'utterance-sharded x%d, no collective' % joined)
+        line = {'metric': 'mel frames/sec', 'value': round(frames * joined * args.steps / dt, 1), 'unit': 'frames/s',
+                'n_gpus': joined, 'steps': args.steps, 'warmup': args.warmup,
                 'ms_per_step': round(dt / args.steps * 1e3, 5), 'higher_is_better': True, 'scaling': 'weak',
-                'vs_baseline': None, 'dtype': 'f32' if args.workload in ('frontend', 'train', 'vocoder') else
+                'vs_baseline': None, 'dtype': 'f32' if args.workload in ('frontend', 'train', 'vocoder', 'stub') else
                 ('bf16' if args.dtype == 'bfloat16' else 'f32'), 'data': 'synthetic',
-                'config': dict(cfg, parallelism='utterance-sharded x%d, no collective' % world)}
+                'config': dict(cfg, parallelism=par)}
         line.update(extra)
-        if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = {'frontend': cpu_baseline_frontend, 'vocoder': cpu_baseline_vocoder}.get(
-                args.workload, cpu_baseline_full)()
-        print(json.dumps(line))
+        if joined == 1 and not args.no_cpu_baseline and not stub:
+            line['cpu_baseline'] = {'frontend': cpu_baseline_frontend, 'vocoder': cpu_baseline_vocoder,
+                                    'train': cpu_baseline_train}.get(args.workload, cpu_baseline_full)()
+        print(json.dumps(line), flush=True)
     dist_util.finalize()
 
 

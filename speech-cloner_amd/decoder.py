@@ -197,6 +197,13 @@ class decoder_specs:
                     self.opt_state[k] = w[k]
             self.i_global_step = int(self.opt_state['dec_opt/global_step'])
             self.i_epoch = int(self.opt_state['dec_opt/epoch'])
+            if self.cfg_d['is_training']:
+                # tf.train.Saver restores the Adam slots (dec_opt/<var>/Adam, Adam_1) and the step with the weights:
+                # an existing trainer takes them now, a later one when it is created (_get_trainer)
+                if getattr(self, '_trainer', None) is not None:
+                    self._trainer.resume(w)
+                else:
+                    self._restored_ckpt = w
             print('Restored: "{}"'.format(save_path))
         except Exception:
             print(' Model not found: {}'.format(save_path), file=sys.stderr)
@@ -309,6 +316,9 @@ class decoder_specs:
         if getattr(self, '_trainer', None) is None:
             import training
             self._trainer = training.DecoderTrainer(self)
+            if getattr(self, '_restored_ckpt', None) is not None:      # resume Adam state like tf.train.Saver
+                self._trainer.resume(self._restored_ckpt)
+                self._restored_ckpt = None
         return self._trainer
 
     def exec_train_step(self, inputs, target_mel, target_stft):

@@ -173,10 +173,6 @@ class encoder_spec_phn:
             names = None if self.cfg_d['is_training'] else \
                 set(n for n in self.store.vars if n.startswith(self._scope + '/')) | set(self.opt_state)
             w = tf_bundle.read_bundle(save_path, verify_crc=True, names=names)
-            if self.cfg_d['is_training']:              # Adam slots are picked up when the trainer is created
-                self._restored_ckpt = w
-                if getattr(self, '_trainer', None) is not None:
-                    self._trainer.load_slots(w)
             self.store.load_dict({k: v for k, v in w.items() if k in self.store.vars}, strict=False)
             missing = [n for n in self.store.vars if n.startswith(self._scope + '/') and n not in w]
             if missing:
@@ -186,6 +182,11 @@ class encoder_spec_phn:
                     self.opt_state[k] = w[k]
             self.i_global_step = int(self.opt_state['opt/global_step'])
             self.i_epoch = int(self.opt_state['opt/epoch'])
+            if self.cfg_d['is_training']:              # Adam slots + step: now, or when the trainer is created
+                if getattr(self, '_trainer', None) is not None:
+                    self._trainer.resume(w)
+                else:
+                    self._restored_ckpt = w
             print('Restored: "{}"'.format(save_path))
         except Exception:
             print(' Model not found: {}'.format(save_path), file=sys.stderr)
@@ -240,7 +241,7 @@ class encoder_spec_phn:
             import training
             self._trainer = training.EncoderTrainer(self)
             if getattr(self, '_restored_ckpt', None) is not None:      # resume Adam state like tf.train.Saver
-                self._trainer.load_slots(self._restored_ckpt)
+                self._trainer.resume(self._restored_ckpt)
                 self._restored_ckpt = None
         return self._trainer
 

@@ -44,6 +44,11 @@ def _p(t):
 class _Ops:
     """Thin wrappers over the training entry points (float32 device tensors)."""
 
+    # vc_wgrad_desc.splits_allowed: the frame reduction of a weight gradient may be split over several workgroups that
+    # add their partial sums with atomics (the gradient arena is zeroed at the start of every step).  0 = one
+    # workgroup per tile, fixed summation order (tests compare the two).
+    splits_allowed = 1
+
     @staticmethod
     def transpose(X, M, Cn, ld, T, scale=None, shift=None, relu=0, pool=0, row_shift=0):
         """-> (buffer [Cn, M + 2*MARGIN] zero-initialised, ldt).  Data starts at column MARGIN."""
@@ -60,7 +65,7 @@ class _Ops:
         d = _vc.WgradDesc()
         d.d_XT = XT.data_ptr() + MARGIN * 4
         d.ldxt, d.ldyt, d.Cin, d.M, d.T, d.margin, d.n_groups = ldxt, ldyt, Cin, M, T, MARGIN, len(groups)
-        d.splits_allowed = 1                      # the gradient arena is zeroed at the start of every step
+        d.splits_allowed = int(_Ops.splits_allowed)
         for i, (roff, N, taps, shift0, dW, ldw) in enumerate(groups):
             g = d.groups[i]
             g.d_dYT = dYT.data_ptr() + (roff * ldyt + MARGIN) * 4
@@ -143,6 +148,12 @@ class StageTrainer:
             if km in ckpt and kv in ckpt:
                 m.copy_(torch.from_numpy(np.ascontiguousarray(ckpt[km], dtype=np.float32)))
                 v.copy_(torch.from_numpy(np.ascontiguousarray(ckpt[kv], dtype=np.float32)))
+
+    def resume(self, ckpt):
+        """Everything tf.train.Saver.restore brings back besides the weights: Adam slots and the step the bias
+        correction counts from (the model's opt_state was already updated from the same checkpoint)."""
+        self.load_slots(ckpt)
+        self.step_count = int(self.dec.opt_state[self.opt_scope + '/global_step'])
 
     def slot_dict(self):
         """Adam slots + beta powers under TF's names, for save()."""

@@ -135,6 +135,127 @@ def test_train_checkpoint_has_adam_slots(tmp_path):
     assert ck['dec_opt/' + k + '/Adam'].shape == ck[k].shape and np.abs(ck['dec_opt/' + k + '/Adam_1']).max() > 0
 
 
+def test_restore_resumes_adam_state_and_step(tmp_path, capsys):
+    """save -> restore -> one step equals the uninterrupted run: tf.train.Saver brings back the Adam slots
+    (dec_opt/<var>/Adam, Adam_1) and global_step with the weights (decoder.py:309-324).  Without them the first
+    update after a resume is ~3x lr (m = v = 0 at a bias correction of ~1) and differs at the 1e-3 level."""
+    cfg = _cfg()
+    cfg['model_path'] = str(tmp_path)
+    dec, w, ppg, t_mel, t_stft = _setup(cfg)
+    for _ in range(2):
+        dec.exec_train_step(ppg, t_mel, t_stft)
+    dec.save(verbose=False)
+    r3 = dec.exec_train_step(ppg, t_mel, t_stft)
+    want = {n: v.clone() for n, v in dec.store.vars.items()}
+    want_m = dec._trainer.m.clone()
+
+    def check(d, what):
+        worst = max(float((d.store.vars[n] - want[n]).abs().max()) for n in want)
+        assert worst < 2e-6, '%s: parameters differ from the uninterrupted run by %.3e' % (what, worst)
+        assert float((d._trainer.m - want_m).abs().max()) < 1e-6 * max(1.0, float(want_m.abs().max()))
+
+    # (a) restore into a fresh model: the trainer does not exist yet and picks the slots up when it is created
+    cfg2 = _cfg()
+    cfg2['model_path'] = str(tmp_path)
+    dec2, _, _, _, _ = _setup(cfg2, seed=11)
+    dec2.restore()
+    assert dec2.i_global_step == 2 and int(dec2.opt_state['dec_opt/global_step']) == 2
+    q3 = dec2.exec_train_step(ppg, t_mel, t_stft)
+    assert q3[3] == 3 and abs(q3[2] - r3[2]) < 1e-4 * max(1.0, abs(r3[2]))
+    check(dec2, 'fresh model')
+    # (b) restore into a model whose trainer already exists (its step count and slots were stale)
+    dec2.restore()
+    assert dec2._trainer.step_count == 2
+    q3 = dec2.exec_train_step(ppg, t_mel, t_stft)
+    assert q3[3] == 3
+    check(dec2, 'existing trainer')
+
+
+def _hp_cfg(seed=77):
+    import os
+    from conftest import ROOT
+    cfg = json.load(open(os.path.join(ROOT, 'speech-cloner_amd', 'hp', 'decoder_cfg_d.json')))
+    cfg.update(is_training=True, dropout_seed=seed)
+    return cfg
+
+
+def test_hp_size_train_step_matches_autograd():
+    """SURVEY section 8 row a23 at the SHIPPED sizes (hp/decoder_cfg_d.json: E = 256 / 512, K = 32 banks, 4 / 6
+    highway layers, T = 400; /root/reference/decoder.py:185-263, 327-345): one decoder step on 2 windows -- both
+    losses, every gradient (grouped K = 32 weight-gradient launches, H = 128 / 256 recurrences through time), the
+    moving statistics and one Adam update -- against autograd on the float64 oracle with the same dropout masks.
+    Tolerances as at the small configuration: losses 1e-5 relative, outputs 1e-4, gradients 2e-3 of each tensor's
+    max |gradient| (float32 MFMA sums over 800 frames and up to 8,192 products vs float64), Adam 5e-6."""
+    cfg = _hp_cfg()
+    assert cfg['steps_v'][0]['num_conv_banks'] == 32 and cfg['steps_v'][1]['embed_size'] == 512
+    dec, w, ppg, t_mel, t_stft = _setup(cfg, N=2)
+    tr = dec._get_trainer()
+    assert tr.total == 33186713                                   # SURVEY section 8a row a20: trainable parameters
+    x = torch.from_numpy(ppg).cuda()
+    losses = tr.forward_backward(x, torch.from_numpy(t_mel).cuda(), torch.from_numpy(t_stft).cuda())
+    got = losses.cpu().numpy()
+    g_dev = {n: tr.g(n).cpu().numpy().astype(np.float64) for n in tr.names}
+    y_mel, y_stft = tr.y_mel.cpu().numpy(), tr.y_stft.cpu().numpy()
+    moved = {n: dec.store.vars[n].cpu().numpy() for n in dec.store.vars if n in dec.store.non_trainable}
+    p_before = {n: dec.store.vars[n].cpu().numpy().astype(np.float64) for n in
+                ('decoder/step2/CBHG/conv1d_banks/num_32/conv1d/conv1d/kernel', 'decoder/step1/CBHG/conv1d_1/conv1d/kernel',
+                 'decoder/step2/CBHG/gru/bidirectional_rnn/fw/gru_cell/gates/kernel', 'decoder/step1/y_logits/bias')}
+    step = tr.apply_gradients(1)
+    assert step == 1
+    ml, sl, grads, stats, ym, ys = _oracle_step(cfg, w, ppg, t_mel, t_stft, tr.seed)
+    assert abs(got[0] - ml) < 1e-5 * max(1, ml) and abs(got[1] - sl) < 1e-5 * max(1, sl), (got, ml, sl)
+    assert np.abs(y_mel.reshape(ym.shape) - ym).max() < 1e-4 * max(1.0, np.abs(ym).max())
+    assert np.abs(y_stft.reshape(ys.shape) - ys).max() < 1e-4 * max(1.0, np.abs(ys).max())
+    assert set(grads) == set(tr.names)
+    worst = ('', 0.0)
+    for n in tr.names:
+        ref = grads[n]
+        assert g_dev[n].shape == ref.shape, n
+        err = np.abs(g_dev[n] - ref).max() / max(np.abs(ref).max(), 1e-6)
+        if err > worst[1]:
+            worst = (n, err)
+    print('hp-size train step: worst gradient mismatch %s %.3e' % worst)
+    assert worst[1] < 2e-3, 'worst gradient mismatch %s: %.3e' % worst
+    for n, v in stats.items():
+        assert np.abs(moved[n] - v.numpy()).max() < 1e-5 * max(1.0, float(v.abs().max())), n
+    for n, p0 in p_before.items():
+        p, m, v = mo.adam_step(torch.from_numpy(p0), torch.from_numpy(grads[n]), 0.0, 0.0, 1, 1e-3)
+        assert np.abs(dec.store.vars[n].cpu().numpy() - p.numpy()).max() < 5e-6, n
+
+
+def test_hp_size_split_weight_gradients_equal_unsplit_at_32_windows():
+    """BASELINE configs[4]'s per-GPU shape (32 windows x 400 frames, shipped sizes): the weight-gradient launches split
+    their frame reduction over workgroups and add partial sums with atomics (splits_allowed); that must equal the
+    unsplit, fixed-order reduction within float32 summation noise (1e-4 of each tensor's max |gradient|; 12,800-frame
+    sums), and the loss must not depend on it at all."""
+    import training
+    cfg = _hp_cfg()
+    dec, w, ppg, t_mel, t_stft = _setup(cfg, N=32)
+    tr = dec._get_trainer()
+    args = [torch.from_numpy(a).cuda() for a in (ppg, t_mel, t_stft)]
+    res = {}
+    try:
+        for splits in (1, 0):
+            training._Ops.splits_allowed = splits
+            l = tr.forward_backward(*args).cpu().numpy().copy()
+            res[splits] = (l, tr.grad.clone())
+    finally:
+        training._Ops.splits_allowed = 1
+    assert np.array_equal(res[0][0], res[1][0]) and np.isfinite(res[0][0]).all()
+    worst = ('', 0.0)
+    for n in tr.names:
+        off, k, _ = tr.offsets[n]
+        a, b = res[1][1][off:off + k], res[0][1][off:off + k]
+        err = float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+        if err > worst[1]:
+            worst = (n, err)
+    print('split vs unsplit weight gradients: worst %s %.3e' % worst)
+    assert worst[1] < 1e-4, worst
+    # moving statistics moved twice by the same batch: finite and changed (the step is usable at this shape)
+    r = dec.exec_train_step(ppg, t_mel, t_stft)
+    assert r[3] == 1 and np.isfinite(r[2])
+
+
 _DP_WORKER = r'''
 import os, sys, json
 import numpy as np, torch
