@@ -106,14 +106,19 @@ def bn(x, w, scope, is_training=False, stats_out=None):
     return (x - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta
 
 
-def conv1d_banks(x, w, scope, K, is_training=False, stats_out=None):
+def conv1d_banks(x, w, scope, K, is_training=False, stats_out=None, taps=None):
     """modules.py:144-166: K convs of width 1..K (each 128 filters in every shipped model --
-    called without embed_size at modules.py:328), concat, bn, relu."""
+    called without embed_size at modules.py:328), concat, bn, relu.
+    ``taps``: optional dict that receives 'banks_pre', the normalised pre-activations (tests use them to
+    tell which channels have a frame sitting on the relu kink)."""
     outs = [conv1d(x, w[scope + '/conv1d/conv1d/kernel'])]
     for k in range(2, K + 1):
         outs.append(conv1d(x, w[scope + '/num_%d/conv1d/conv1d/kernel' % k]))
     y = torch.cat(outs, dim=-1)
-    return torch.relu(bn(y, w, scope + '/bn', is_training, stats_out))
+    pre = bn(y, w, scope + '/bn', is_training, stats_out)
+    if taps is not None:
+        taps['banks_pre'] = pre.detach()
+    return torch.relu(pre)
 
 
 def max_pool_2_same(x):
@@ -157,7 +162,7 @@ def gru_bidirectional(x, w, scope):
 
 def cbhg(x, w, scope, K, n_highway, is_training=False, stats_out=None, taps=None):
     """modules.py:323-356.  ``taps``: optional dict that receives intermediate tensors."""
-    y = conv1d_banks(x, w, scope + '/conv1d_banks', K, is_training, stats_out)
+    y = conv1d_banks(x, w, scope + '/conv1d_banks', K, is_training, stats_out, taps=taps)
     if taps is not None:
         taps['banks'] = y
     y = max_pool_2_same(y)

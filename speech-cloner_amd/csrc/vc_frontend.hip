@@ -13,12 +13,14 @@
 // HBM bound: algorithmic traffic is 1,764 B/frame at the shipped config;
 // this 2-pass form moves the raw dB tiles twice (second read mostly from Infinity Cache).
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
 
 #include "vc_common.h"
 #include "fe_dft400.h"
+#include "vc_frontend400.h"
 
 namespace {
 
@@ -622,9 +624,11 @@ struct vc_frontend_plan {
     vc_frontend_cfg cfg;
     int n_bins, mfcc_width, nnz;
     bool fft400;
+    bool fast400;                 // shipped configuration: the two-launch path of vc_frontend400.hip
     std::vector<double> mel, dct;
     void* d_blob;
     FeDev dev;
+    const float* d_dct_half;      // [n_mfcc][n_mels / 2] (fast400 only)
 };
 
 extern "C" {
@@ -686,8 +690,16 @@ int vc_frontend_plan_create(const vc_frontend_cfg* cfg, const double* h_window, 
     std::vector<float> dctf((size_t)NC * NM);
     for (size_t i = 0; i < dctf.size(); ++i) dctf[i] = (float)p->dct[i];
 
-    // one device blob: window | tw400 | twg | mel_w | dct | mel_start | mel_off
-    const size_t n_f = (size_t)N + 416 + 2 * (size_t)N + mw.size() + dctf.size();
+    int max_cnt = 0;
+    for (int m = 0; m < NM; ++m) max_cnt = std::max(max_cnt, (int)(moff[m + 1] - moff[m]));
+    p->fast400 = p->fft400 && cfg->hop_length == 80 && NM == 80 && NC == 40 && max_cnt <= 14;
+    std::vector<float> dcth((size_t)NC * (NM / 2));
+    for (int i = 0; i < NC; ++i)
+        for (int j = 0; j < NM / 2; ++j) dcth[(size_t)i * (NM / 2) + j] = (float)p->dct[(size_t)i * NM + j];
+    // one device blob: window | tw400 | twg | mel_w | dct | (pad to 16 B) dct_half | mel_start | mel_off
+    const size_t pre_f = (size_t)N + 416 + 2 * (size_t)N + mw.size() + dctf.size();
+    const size_t pad_f = (4 - pre_f % 4) % 4;
+    const size_t n_f = pre_f + pad_f + dcth.size();
     const size_t n_i = (size_t)NM + NM + 1;
     std::vector<char> host(n_f * 4 + n_i * 4);
     float* hf = reinterpret_cast<float*>(host.data());
@@ -697,6 +709,8 @@ int vc_frontend_plan_create(const vc_frontend_cfg* cfg, const double* h_window, 
     const size_t o_twg = o; std::memcpy(hf + o, twg.data(), 2 * (size_t)N * 4); o += 2 * (size_t)N;
     const size_t o_mw = o; if (!mw.empty()) std::memcpy(hf + o, mw.data(), mw.size() * 4); o += mw.size();
     const size_t o_dct = o; std::memcpy(hf + o, dctf.data(), dctf.size() * 4); o += dctf.size();
+    o += pad_f;
+    const size_t o_dcth = o; std::memcpy(hf + o, dcth.data(), dcth.size() * 4); o += dcth.size();
     int32_t* hi = reinterpret_cast<int32_t*>(hf + o);
     std::memcpy(hi, mstart.data(), NM * 4);
     std::memcpy(hi + NM, moff.data(), (NM + 1) * 4);
@@ -711,6 +725,7 @@ int vc_frontend_plan_create(const vc_frontend_cfg* cfg, const double* h_window, 
     p->dev.twg = df + o_twg;
     p->dev.mel_w = df + o_mw;
     p->dev.dct = df + o_dct;
+    p->d_dct_half = df + o_dcth;
     p->dev.mel_start = reinterpret_cast<int32_t*>(df + o);
     p->dev.mel_off = p->dev.mel_start + NM;
     *out_plan = p;
@@ -773,6 +788,23 @@ int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, con
     if (workspace_bytes < total) return vc::set_error(VC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, total);
 
     const vc_frontend_cfg& c = plan->cfg;
+    if (plan->fast400) {
+        // shipped configuration: statistics pass + feature pass, every output byte written once (vc_frontend400.hip)
+        Fe400Args f;
+        f.wav = d_wav; f.lens = d_lens; f.max_samples = max_samples; f.wav_stride = wav_stride; f.max_frames = max_frames;
+        f.win_tw = plan->dev.window;                    // window[400] | tw400[416] are adjacent in the blob
+        f.mel_w = plan->dev.mel_w; f.mel_start = plan->dev.mel_start; f.mel_off = plan->dev.mel_off;
+        f.dct_half = plan->d_dct_half;
+        f.pre_emph = c.pre_emphasis; f.amp_norm = c.mean_abs_amp_norm;
+        f.mfcc_norm = c.mfcc_norm_factor; f.m_norm = c.M_dB_norm_factor; f.p_norm = c.P_dB_norm_factor;
+        f.first_mfcc = c.mfcc_normaleze_first_mfcc; f.deriv = c.calc_mfcc_derivate; f.clip = c.clip_output;
+        char* wsb = static_cast<char*>(d_workspace);
+        f.stats = reinterpret_cast<float*>(wsb + o_stats);
+        f.mel0 = reinterpret_cast<float*>(wsb + o_mel);
+        f.nt1 = ntiles;
+        f.mfcc = d_mfcc; f.mel_db = d_mel_db; f.pow_db = d_pow_db;
+        return vc_fe400_launch(f, batch, stage_mask, static_cast<hipStream_t>(stream));
+    }
     const int G = plan->fft400 ? FE_G400 : FE_GGEN;
     FeArgs a;
     a.t = plan->dev;

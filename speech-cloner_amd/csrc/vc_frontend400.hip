@@ -1,0 +1,448 @@
+// Signal front-end, shipped configuration (n_fft = 400, hop = 80, 80 mels, 40 cepstra): two launches,
+// every output byte written exactly once (/root/reference/audio_lib.py:89-244).
+//
+//   pass 1  fe400_kernel<true>    16 frames per block: gather + reflect + pre-emphasis -> windowed 400-point real
+//                                 DFT (25 x 16 split, fe_dft400.h) -> |.|^2 -> sparse Slaney mel; keeps ONLY the
+//                                 tile's max / min of the power and of the mel power (linear: the dB maps are
+//                                 monotone), sum|x| of its own samples, and frame 0's mel row.  Reads 320 B/frame,
+//                                 writes 32 B per tile.
+//   pass 2  fe400_kernel<false>   16 frames per block (14 output frames + one halo frame each side for the deltas):
+//                                 the same transform again, then -- with the utterance's extremes known --
+//                                 power_to_db + top_db clip + min shift + scale + clip -> P_dB, amplitude_to_db of
+//                                 the mel POWER (the reference's quirk, audio_lib.py:172) -> M_dB, DCT-II (using
+//                                 D[i][79-j] = (-1)^i D[i][j]: 40 instead of 80 products per coefficient), frame-0
+//                                 shift, scale, delta, clip -> MFCC.  Reads 320 B/frame again (L2 / Infinity Cache
+//                                 hits), writes 1,444 B/frame once.
+// HBM traffic: 2 x 320 + 1,444 = 2,084 B/frame against 1,764 algorithmic (1.18x); the three-launch form in
+// vc_frontend.hip (kept for every other configuration) moves the raw dB tiles through HBM twice (2.4x).
+// Recomputing the transform is the cheaper side of that trade: the kernels are issue- and latency-bound, not
+// byte-bound, and the transform is ~40 % of a pass's instructions.
+#include <hip/hip_runtime.h>
+#include "vc_common.h"
+#include "fe_dft400.h"
+#include "vc_frontend400.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int G = 16;                 // frames transformed per block
+constexpr int GO = 14;                // output frames per block in pass 2
+constexpr int HOP = 80, NFFT = 400, HALF = 200, NB = 201, NM = 80, NC = 40, NH = 40;
+constexpr int SPAN = HOP * (G - 1) + NFFT;          // 1600 samples under a tile's 16 frames
+constexpr int ROWS = G * 13;                        // (frame, k1) rows of the 16-point stage
+constexpr int PT_FLOATS = ROWS * 16;                // one row buffer (3328 floats) >= 16 * 201 + 16 (power tile + pad)
+constexpr float NEG_INF = -3.402823466e38f, POS_INF = 3.402823466e38f;
+constexpr float DB10 = 3.0102999566398120f;         // 10 log10(x) = DB10 * log2(x)
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+// LDS carve (floats): xs | A_re | A_im | scalars.  (Reading the samples straight from global memory in the 25-point
+// stage -- no sample buffer, one barrier fewer -- measured 6-12 % SLOWER: 50 loads per thread against 14.)
+constexpr int O_XS = 0, O_ARE = SPAN, O_AIM = O_ARE + PT_FLOATS, O_SC = O_AIM + PT_FLOATS, LDS_FLOATS = O_SC + 48;
+static_assert(PT_FLOATS >= G * NB + 16, "power tile aliases a row buffer");
+static_assert(G * NM <= SPAN, "mel dB tile aliases the sample buffer");
+static_assert(G * NC + G * NM <= PT_FLOATS, "cepstra + sum/difference tiles alias the second row buffer");
+
+__device__ __forceinline__ int utt_len(const Fe400Args& a, int b) {
+    const int L = a.lens ? a.lens[b] : a.max_samples;
+    return min(max(L, 1), a.max_samples);
+}
+
+// amplitude_to_db applied to the mel POWER (audio_lib.py:172: 10 log10(max(1e-10, v^2)) = 20 log10(max(1e-5, v))), the
+// amplitude-normalisation offset, and the top_db floor.  One function: frame 0's reference value and the tile's own
+// values must round identically.  (The amin clamp -100 dB is below every floor: floor >= -100.)
+__device__ __forceinline__ float mel_db_clipped(float v, float offm, float mfloor) {
+    return fmaxf(fmaf(2.0f * DB10, __log2f(fmaxf(v, 1e-18f)), offm), mfloor);
+}
+
+// physical float index of element n2 of row r in a row buffer: 16 floats per row, the 16-byte chunk XORed with
+// (r >> 2) & 3 so that the 16 lanes of a ds_read_b128 group (16 consecutive rows) hit 16 different 4-bank groups
+__device__ __forceinline__ int row_at(int r, int n2) { return r * 16 + ((((n2 >> 2) ^ (r >> 2)) & 3) << 2) + (n2 & 3); }
+
+template <bool STATS>
+__global__ void __launch_bounds__(NT, 4)
+fe400_kernel(Fe400Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const xs = smem + O_XS;
+    float* const Are = smem + O_ARE;
+    float* const Aim = smem + O_AIM;
+    float* const sc = smem + O_SC;
+    float* const Pt = Are;                              // [G][201] (+ pad) once the rows are in registers
+
+    const int tid = threadIdx.x, b = blockIdx.y;
+    const int L = utt_len(a, b);
+    const int F = 1 + L / HOP;
+    // first transformed frame of the tile (pass 2: one halo frame ahead of the first output frame)
+    const int fo = (STATS ? G : GO) * (int)blockIdx.x;          // first frame this block is responsible for
+    const int f0 = STATS ? fo : fo - 1;
+    const size_t row0 = (size_t)b * a.max_frames;
+
+    if (fo >= F) {
+        if constexpr (STATS) {
+            if (tid == 0) {
+                float* s = a.stats + ((size_t)b * a.nt1 + blockIdx.x) * 8;
+                s[0] = NEG_INF; s[1] = POS_INF; s[2] = NEG_INF; s[3] = POS_INF; s[4] = 0.0f;
+            }
+        } else {                                        // padding rows of a ragged batch: zeros
+            const int nrows = min(GO, a.max_frames - fo);
+            const int mw = a.deriv ? 2 * NC : NC;
+            float* o1 = a.mfcc + (row0 + fo) * mw;
+            float* o2 = a.mel_db + (row0 + fo) * NM;
+            float* o3 = a.pow_db + (row0 + fo) * NB;
+            for (int i = tid; i < nrows * mw; i += NT) o1[i] = 0.0f;
+            for (int i = tid; i < nrows * NM; i += NT) o2[i] = 0.0f;
+            for (int i = tid; i < nrows * NB; i += NT) o3[i] = 0.0f;
+        }
+        return;
+    }
+
+    // ---------------- tables this thread needs in registers (L2 hits; issued before anything waits)
+    const int g = tid >> 4, n2 = tid & 15;
+    float wreg[25];
+#pragma unroll
+    for (int n1 = 0; n1 < 25; ++n1) wreg[n1] = a.win_tw[16 * n1 + n2];
+
+    // ---------------- samples: reflect padding of the pre-emphasised signal (np.pad(y_preem, 200, 'reflect'))
+    // The amplitude normalisation (audio_lib.py:125-126: y *= norm / mean|y|) is linear all the way to the power
+    // spectrum, so it is applied as a dB offset once mean|y| is known (pass 2).
+    const float* x = a.wav + (size_t)b * a.wav_stride;
+    const int base = f0 * HOP - HALF;
+    float asum = 0.0f;
+    {
+        const bool interior = base >= 1 && base + SPAN <= L;    // block-uniform: no reflection, no clamping
+        const float pe = a.pre_emph;
+        float cur[7], prv[7];
+        if (interior) {
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int i = min(tid + NT * u, SPAN - 1);
+                cur[u] = x[base + i];
+                prv[u] = x[base + i - 1];
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 7; ++u) {
+                const int idx = base + min(tid + NT * u, SPAN - 1);
+                int j = idx < 0 ? -idx : (idx >= L ? 2 * (L - 1) - idx : idx);
+                j = min(max(j, 0), L - 1);
+                cur[u] = x[j];
+                prv[u] = j > 0 ? x[j - 1] : 0.0f;               // lfilter's zero initial state: y[0] = x[0]
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int i = tid + NT * u;
+            if (i < SPAN) {
+                const int idx = base + i;
+                // beyond the reflected tail (idx >= L + 200) no frame of this utterance reads
+                xs[i] = idx < L + HALF ? cur[u] - pe * prv[u] : 0.0f;
+                if constexpr (STATS) {
+                    // sum|x| of the tile's OWN samples [fo*80, (fo+16)*80): every sample counted once per utterance
+                    if (idx >= fo * HOP && idx < min((fo + G) * HOP, L)) asum += fabsf(cur[u]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- steps 1 + 2: thread (g, n2): real 25-point DFT over n1, twiddle W400^(n2 k1)
+    {
+        const float* xp = xs + g * HOP + n2;
+        float v[25], ar[13], ai[13];
+#pragma unroll
+        for (int n1 = 0; n1 < 25; ++n1) v[n1] = xp[16 * n1] * wreg[n1];
+        // twiddles: requested here, consumed behind the 25-point transform
+        float twr[13], twi[13];
+#pragma unroll
+        for (int k1 = 1; k1 < 13; ++k1) { twr[k1] = a.win_tw[400 + k1 * 16 + n2]; twi[k1] = a.win_tw[608 + k1 * 16 + n2]; }
+        vcfe::rdft25_13(v, ar, ai);
+        const int r0 = g * 13;
+        Are[row_at(r0, n2)] = ar[0];
+        Aim[row_at(r0, n2)] = ai[0];
+#pragma unroll
+        for (int k1 = 1; k1 < 13; ++k1) {
+            vcfe::cmul(ar[k1], ai[k1], twr[k1], twi[k1]);
+            Are[row_at(r0 + k1, n2)] = ar[k1];
+            Aim[row_at(r0 + k1, n2)] = ai[k1];
+        }
+    }
+    __syncthreads();
+
+    // ---------------- step 3: thread (g3, k13) = row tid: complex 16-point DFT over n2 -> |Y|^2
+    const int g3 = tid / 13, k13 = tid - g3 * 13;
+    const bool row_ok = tid < ROWS;
+    float pw[16];
+    {
+        float zr[16], zi[16], yr[16], yi[16];
+        const int r = row_ok ? tid : 0;
+        const int key = (r >> 2) & 3;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f4 vr = *reinterpret_cast<const f4*>(Are + r * 16 + ((q ^ key) << 2));
+            const f4 vi = *reinterpret_cast<const f4*>(Aim + r * 16 + ((q ^ key) << 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { zr[4 * q + e] = vr[e]; zi[4 * q + e] = vi[e]; }
+        }
+        vcfe::cdft16(zr, zi, yr, yi);
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) pw[k2] = yr[k2] * yr[k2] + yi[k2] * yi[k2];
+    }
+    __syncthreads();                                    // every row is in registers: the row buffers are free
+    // power tile: bin k1 + 25 k2 directly for k2 <= 7 (and 200 = 0 + 25 * 8); the bins with residue 13..24 are the
+    // mirror images 400 - k of the outputs with k2 >= 8 (hermitian symmetry, fe_dft400.h bin_of)
+    float pmax = NEG_INF, pmin = POS_INF;
+    const bool frame_ok = row_ok && (f0 + g3 >= 0) && (f0 + g3 < F);
+    if (row_ok) {
+        float* pg = Pt + g3 * NB;
+#pragma unroll
+        for (int k2 = 0; k2 < 8; ++k2) pg[k13 + 25 * k2] = pw[k2];
+        if (k13 == 0) pg[200] = pw[8];
+        else {
+#pragma unroll
+            for (int k2 = 8; k2 < 16; ++k2) pg[400 - 25 * k2 - k13] = pw[k2];
+        }
+        if constexpr (STATS) {
+            if (frame_ok) {
+#pragma unroll
+                for (int k2 = 0; k2 < 8; ++k2) { pmax = fmaxf(pmax, pw[k2]); pmin = fminf(pmin, pw[k2]); }
+                if (k13 == 0) { pmax = fmaxf(pmax, pw[8]); pmin = fminf(pmin, pw[8]); }
+                else {
+#pragma unroll
+                    for (int k2 = 8; k2 < 16; ++k2) { pmax = fmaxf(pmax, pw[k2]); pmin = fminf(pmin, pw[k2]); }
+                }
+            }
+        }
+    }
+    if (tid < 16) Pt[G * NB + tid] = 0.0f;              // pad behind the last row: the mel loop reads past a row's end
+
+    // ---------------- sparse mel: thread (m, frame group): filter m's <= 14 weights in registers
+    const int mm = tid % NM, mg = tid / NM;             // mg = 3: idle lanes of the last wave
+    float mw_[14];
+    int ms = 0, mcnt = 0;
+    if (mg < 3) {
+        ms = a.mel_start[mm];
+        const int o = a.mel_off[mm];
+        mcnt = a.mel_off[mm + 1] - o;
+#pragma unroll
+        for (int j = 0; j < 14; ++j) mw_[j] = j < mcnt ? a.mel_w[o + j] : 0.0f;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 14; ++j) mw_[j] = 0.0f;
+    }
+    int wcnt = mcnt;                                    // wave-uniform trip count
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wcnt = max(wcnt, __shfl_xor(wcnt, o, 64));
+    wcnt = __builtin_amdgcn_readfirstlane(wcnt);
+
+    if constexpr (STATS) {
+        float mmax = NEG_INF, mmin = POS_INF;
+        __syncthreads();                                // power tile complete
+        if (mg < 3) {
+            for (int gg = mg; gg < G; gg += 3) {
+                const float* p = Pt + gg * NB + ms;
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 14; ++j)
+                    if (j < wcnt) acc = fmaf(mw_[j], p[j], acc);
+                if (f0 + gg < F) { mmax = fmaxf(mmax, acc); mmin = fminf(mmin, acc); }
+                if (f0 + gg == 0) a.mel0[(size_t)b * NM + mm] = acc;
+            }
+        }
+        pmax = vc::wave_max(pmax); pmin = vc::wave_min(pmin);
+        mmax = vc::wave_max(mmax); mmin = vc::wave_min(mmin);
+        asum = vc::wave_sum(asum);
+        const int w = tid >> 6;
+        if ((tid & 63) == 0) { sc[w * 5 + 0] = pmax; sc[w * 5 + 1] = pmin; sc[w * 5 + 2] = mmax; sc[w * 5 + 3] = mmin; sc[w * 5 + 4] = asum; }
+        __syncthreads();
+        if (tid == 0) {
+#pragma unroll
+            for (int i = 1; i < NT / 64; ++i) {
+                pmax = fmaxf(pmax, sc[i * 5 + 0]); pmin = fminf(pmin, sc[i * 5 + 1]);
+                mmax = fmaxf(mmax, sc[i * 5 + 2]); mmin = fminf(mmin, sc[i * 5 + 3]);
+                asum += sc[i * 5 + 4];
+            }
+            float* s = a.stats + ((size_t)b * a.nt1 + blockIdx.x) * 8;
+            s[0] = pmax; s[1] = pmin; s[2] = mmax; s[3] = mmin; s[4] = asum;
+        }
+        return;
+    } else {
+        // ---------------- per-utterance constants from pass 1's tile records (wave 0)
+        float* const Mc = xs;                           // [G][80]  clipped mel dB (the samples are consumed)
+        float* const Mf = Aim;                          // [G][40]  scaled cepstra
+        float* const SD = Aim + G * NC;                 // [G][80]  j < 40: m[j] + m[79-j], j >= 40: m[j-40] - m[119-j]
+        // DCT basis row of this thread's coefficient (rows of librosa.filters.dct(40, 80), first half)
+        const int ci = tid / 6, cf = tid - ci * 6;      // coefficient, frame phase (tid < 240)
+        float drow[NH];
+        if (tid < 240) {
+#pragma unroll
+            for (int j = 0; j < NH; j += 4) {
+                const f4 d = *reinterpret_cast<const f4*>(a.dct_half + ci * NH + j);
+                drow[j] = d[0]; drow[j + 1] = d[1]; drow[j + 2] = d[2]; drow[j + 3] = d[3];
+            }
+        }
+        if (tid < 64) {
+            const int nt = (F + G - 1) / G;
+            float pmx = NEG_INF, pmn = POS_INF, mmx = NEG_INF, mmn = POS_INF, as = 0.0f;
+            for (int t = tid; t < nt; t += 64) {
+                const float* s = a.stats + ((size_t)b * a.nt1 + t) * 8;
+                pmx = fmaxf(pmx, s[0]); pmn = fminf(pmn, s[1]);
+                mmx = fmaxf(mmx, s[2]); mmn = fminf(mmn, s[3]);
+                as += s[4];
+            }
+            pmx = vc::wave_max(pmx); pmn = vc::wave_min(pmn);
+            mmx = vc::wave_max(mmx); mmn = vc::wave_min(mmn);
+            as = vc::wave_sum(as);
+            // amplitude normalisation as dB offsets: c = norm / mean|x| -> + 20 log10 c on the power dB, + 40 log10 c on
+            // the mel dB; then the amin clamps (10 log10 1e-10 = 20 log10 1e-5 = -100 dB) and top_db = 80
+            float offp = 0.0f;
+            if (a.amp_norm != 1.0f) offp = 2.0f * DB10 * __log2f(a.amp_norm / (as / (float)L));
+            const float offm = 2.0f * offp;
+            const float pmax_db = fmaxf(DB10 * __log2f(fmaxf(pmx, 1e-30f)) + offp, -100.0f);
+            const float pmin_db = fmaxf(DB10 * __log2f(fmaxf(pmn, 1e-30f)) + offp, -100.0f);
+            const float mmax_db = fmaxf(2.0f * DB10 * __log2f(fmaxf(mmx, 1e-18f)) + offm, -100.0f);
+            const float mmin_db = fmaxf(2.0f * DB10 * __log2f(fmaxf(mmn, 1e-18f)) + offm, -100.0f);
+            const float pfloor = fmaxf(pmax_db - 80.0f, -100.0f), mfloor = fmaxf(mmax_db - 80.0f, -100.0f);
+            const float pmin_c = fmaxf(pmin_db, pfloor), mmin_c = fmaxf(mmin_db, mfloor);
+            // out = clip(A log2(P) + B', floor') with the min shift and the scale folded in (skipped at factor 1.0,
+            // audio_lib.py:230-235)
+            const bool pn = a.p_norm != 1.0f, mn = a.m_norm != 1.0f;
+            if (tid == 0) {
+                sc[0] = pn ? a.p_norm * DB10 : DB10;
+                sc[1] = pn ? a.p_norm * (offp - pmin_c) : offp;
+                sc[2] = pn ? a.p_norm * (pfloor - pmin_c) : pfloor;
+                sc[3] = offm; sc[4] = mfloor;
+                sc[5] = mn ? a.m_norm : 1.0f;
+                sc[6] = mn ? mmin_c : 0.0f;
+            }
+            // frame 0's first cepstral coefficient (audio_lib.py:221), summed exactly like the tile's own
+            // coefficient 0 below so that frame 0's own value cancels to 0
+            float c00 = 0.0f;
+            if (a.first_mfcc) {
+                const float v0 = tid < NH ? a.mel0[(size_t)b * NM + tid] : 1.0f;
+                const float v1 = tid < NH ? a.mel0[(size_t)b * NM + NM - 1 - tid] : 1.0f;
+                const float d0 = mel_db_clipped(v0, offm, mfloor), d1 = mel_db_clipped(v1, offm, mfloor);
+                const float s0 = d0 + d1;
+                const float dc = a.dct_half[0];                     // row 0 is constant: 1 / sqrt(80)
+                float acc4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < NH; ++j) {
+                    const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s0), j));
+                    acc4[j & 3] = fmaf(dc, sj, acc4[j & 3]);
+                }
+                c00 = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+            }
+            if (tid == 0) sc[7] = c00;
+        }
+        __syncthreads();                                // power tile + constants
+        const float pA = sc[0], pB = sc[1], pF = sc[2], offm = sc[3], mfloor = sc[4], mS = sc[5], mM = sc[6], c00 = sc[7];
+        const int nvalid = min(GO, F - fo);             // output frames that exist
+        const int nrows = min(GO, a.max_frames - fo);   // output rows of the buffers (the rest of them: zeros)
+
+        // ---------------- P_dB: rows 1..14 of the tile are contiguous (pitch 201 = row length)
+        {
+            float* o = a.pow_db + (row0 + fo) * NB;
+            const float* p = Pt + NB;
+            const int tv = nvalid * NB, tr = nrows * NB;
+            const bool clip = a.clip != 0;
+#pragma unroll 4
+            for (int i = tid; i < tr; i += NT) {
+                float w = fmaxf(fmaf(pA, __log2f(p[i]), pB), pF);
+                if (clip) w = fminf(fmaxf(w, -1.0f), 1.0f);
+                o[i] = i < tv ? w : 0.0f;
+            }
+        }
+        // ---------------- mel power -> dB of the "amplitude" (quirk) -> top_db clip: all 16 frames (DCT halo)
+        if (mg < 3) {
+            for (int gg = mg; gg < G; gg += 3) {
+                const float* p = Pt + gg * NB + ms;
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 14; ++j)
+                    if (j < wcnt) acc = fmaf(mw_[j], p[j], acc);
+                Mc[gg * NM + mm] = mel_db_clipped(acc, offm, mfloor);
+            }
+        }
+        __syncthreads();
+        // ---------------- M_dB out (float4 rows) and the sum / difference halves for the DCT
+        {
+            const bool clip = a.clip != 0;
+            f4* o = reinterpret_cast<f4*>(a.mel_db + (row0 + fo) * NM);
+            for (int i = tid; i < nrows * (NM / 4); i += NT) {
+                f4 v = *reinterpret_cast<const f4*>(Mc + NM + 4 * i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float w = mS * (v[e] - mM);
+                    if (clip) w = fminf(fmaxf(w, -1.0f), 1.0f);
+                    v[e] = 4 * i < nvalid * NM ? w : 0.0f;
+                }
+                o[i] = v;
+            }
+            for (int i = tid; i < G * NH; i += NT) {
+                const int gg = i / NH, j = i - gg * NH;
+                const float lo = Mc[gg * NM + j], hi = Mc[gg * NM + NM - 1 - j];
+                SD[gg * NM + j] = lo + hi;
+                SD[gg * NM + NH + j] = lo - hi;
+            }
+        }
+        __syncthreads();
+        // ---------------- DCT-II: coefficient ci (even: sums, odd: differences), frames cf, cf + 6, cf + 12
+        if (tid < 240) {
+            const float norm = a.mfcc_norm;
+            for (int gg = cf; gg < G; gg += 6) {
+                const f4* sd = reinterpret_cast<const f4*>(SD + gg * NM + (ci & 1) * NH);
+                float acc4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int j = 0; j < NH / 4; ++j) {
+                    const f4 s = sd[j];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc4[e] = fmaf(drow[4 * j + e], s[e], acc4[e]);
+                }
+                float acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+                if (ci == 0) acc -= c00;
+                if (norm != 1.0f) acc *= norm;
+                Mf[gg * NC + ci] = acc;
+            }
+        }
+        __syncthreads();
+        // ---------------- [MFCC | delta] out (audio_lib.py:226-228, 238): delta = 2 (M[t+1] - M[t-1]), 0 at both ends
+        {
+            const bool clip = a.clip != 0;
+            const int mw = a.deriv ? 2 * NC : NC;
+            f4* o = reinterpret_cast<f4*>(a.mfcc + (row0 + fo) * mw);
+            const int per_row = mw / 4;
+            for (int i = tid; i < nrows * per_row; i += NT) {
+                const int gg = i / per_row, c = 4 * (i - gg * per_row);
+                const int f = fo + gg;
+                f4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (f < F) {
+                    if (c < NC) {
+                        v = *reinterpret_cast<const f4*>(Mf + (gg + 1) * NC + c);
+                    } else if (f >= 1 && f <= F - 2) {
+                        const f4 nx = *reinterpret_cast<const f4*>(Mf + (gg + 2) * NC + (c - NC));
+                        const f4 pv = *reinterpret_cast<const f4*>(Mf + gg * NC + (c - NC));
+                        v = 2.0f * (nx - pv);
+                    }
+                    if (clip) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fminf(fmaxf(v[e], -1.0f), 1.0f);
+                    }
+                }
+                o[i] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int vc_fe400_launch(const Fe400Args& a, int batch, int stage_mask, hipStream_t st) {
+    const size_t lds = (size_t)LDS_FLOATS * 4;
+    if (stage_mask & 2)
+        hipLaunchKernelGGL(fe400_kernel<true>, dim3(a.nt1, batch), dim3(NT), lds, st, a);
+    if (stage_mask & 4) {
+        const int nt2 = (a.max_frames + GO - 1) / GO;
+        hipLaunchKernelGGL(fe400_kernel<false>, dim3(nt2, batch), dim3(NT), lds, st, a);
+    }
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}

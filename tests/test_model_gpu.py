@@ -204,3 +204,43 @@ def test_first_use_on_side_streams_builds_weight_copies_safely(golden_dir):
         outs.append(dec.predict(x, batch_size=2, n_streams=n_streams))
     for u_, v_ in zip(*outs):
         assert not np.isnan(u_).any() and np.array_equal(u_, v_)
+
+
+def test_forced_mfma_recurrence_on_small_chunks_under_stream_overlap(golden_dir):
+    """Regression case for the one wrong result on record (round 1, gpurun_out/gru_mfma_tests.log: y_stft of a
+    3-stream predict differed from the sequential pass once, with the MFMA recurrence forced onto 2-window chunks).
+    DESIGN.md section 9 audits every launch of that configuration; this test IS that configuration -- MFMA
+    recurrence forced for H = 128 / 256 with 2 of the 16 sequence slots used, chunks of two windows and a ragged
+    last chunk, three and four streams, NaN-poisoned LDS and allocator -- repeated, half of the repeats with an
+    unrelated stream keeping the chip busy with LDS-filling filter-bank launches (timing perturbation)."""
+    import _vc
+    import modules
+    from encoder import encoder_spec_phn
+    from decoder import decoder_specs
+    from conftest import poison_gpu_state
+    g = np.load(os.path.join(golden_dir, 'encoder_fwd.npz'))
+    dec_cfg = json.load(open(os.path.join(HP, 'decoder_cfg_d.json')))
+    dec_cfg['is_training'] = False
+    enc = encoder_spec_phn(_enc_cfg(golden_dir, 'bfloat16'), None)
+    dec = decoder_specs(dec_cfg, None, enc)
+    x = np.concatenate([g['x'], g['x'][::-1] * 0.5, g['x'] * 0.25], 0)         # 9 windows -> 5 chunks of 2
+    noise_stream = torch.cuda.Stream()
+    noise_store = modules.VariableStore('bfloat16')
+    noise_x = torch.randn(16, 400, 256, device='cuda').to(torch.bfloat16)
+    try:
+        _vc.set_option('gru_mfma', 1)
+        a = dec.predict(x, batch_size=2, n_streams=1)
+        assert not any(np.isnan(v).any() for v in a)
+        for rep in range(10):
+            poison_gpu_state()
+            if rep & 1:
+                with torch.cuda.stream(noise_stream), modules.variable_store(noise_store), modules.variable_scope('noise'):
+                    for _ in range(6):
+                        modules.conv1d_banks(noise_x, K=32, is_training=False)
+            b = dec.predict(x, batch_size=2, n_streams=3 + (rep % 3 == 2))
+            for name, u_, v_ in zip(a._fields, a, b):
+                assert np.array_equal(u_, v_), 'repeat %d: %s differs from the sequential pass (max %g)' % (
+                    rep, name, np.abs(u_ - v_).max())
+        torch.cuda.synchronize()
+    finally:
+        _vc.set_option('gru_mfma', -1)
