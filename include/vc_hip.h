@@ -309,6 +309,11 @@ int vc_highway_backward(const float* d_pre, int32_t NP, const float* d_X, const 
 int vc_col_sum(const float* d_X, int32_t M, int32_t C, int32_t ld, float* d_out, int32_t accumulate,
                float* d_workspace, void* stream);
 int vc_fill(float* d_p, float value, size_t n, void* stream);
+/* out[m][c] = a * X[m][c] + b * Y[m][c] over [M, C] float32 views with row strides ldx / ldy / ldo (out may alias X or
+ * Y).  decoder_specs._build_model's teacher-forced stage-2 input, /root/reference/decoder.py:148-152:
+ * inputs_step2 = f_mel_pred * y_mel + (1 - f_mel_pred) * target_mel, and its gradient dY_mel += f_mel_pred * dX. */
+int vc_axpby(const float* d_X, int32_t ldx, float a, const float* d_Y, int32_t ldy, float b, float* d_out, int32_t ldo,
+             int32_t M, int32_t C, void* stream);
 /* loss = weight * mean((y - t)^2) (decoder.py:187-189); optional d_dY = 2*weight/n * (y - t).
  * y/t are contiguous [n/C, C]; d_dY is written with row stride ld_dy >= C (padding columns are
  * left untouched).  d_workspace: 256 floats; d_loss: 1 float on the device (no host sync). */

@@ -200,9 +200,12 @@ def encoder_forward(x, w, cfg, scope=None, taps=None, is_training=False, masks=N
     return logits, pred, cls, out
 
 
-def decoder_forward(ppg, w, cfg, is_training=False, masks=None, stats_out=None, taps=None):
-    """decoder.py:75-182 (use_target_mel_step2 False).  ppg = encoder softmax [N,T,61].
+def decoder_forward(ppg, w, cfg, is_training=False, masks=None, stats_out=None, taps=None, target_mel=None,
+                    f_mel_pred=None):
+    """decoder.py:75-182.  ppg = encoder softmax [N,T,61].
     ``masks``: dict 'step1'/'step2' -> (mask1, mask2) dropout keep-masks for training.
+    ``target_mel`` / ``f_mel_pred``: with cfg['use_target_mel_step2'] the second stage is fed
+    f_mel_pred * y_mel + (1 - f_mel_pred) * target_mel (decoder.py:148-152).
     Returns (y_mel, y_stft)."""
     scope = cfg.get('model_name', 'decoder')
     x = ppg
@@ -223,6 +226,8 @@ def decoder_forward(ppg, w, cfg, is_training=False, masks=None, stats_out=None, 
         y = dense(out, w, s + '/y_logits')
         ys.append(y)
         x = y
+        if i == 0 and cfg.get('use_target_mel_step2', False):
+            x = f_mel_pred * y + (1.0 - f_mel_pred) * target_mel
     return ys[0], ys[1]
 
 

@@ -133,6 +133,7 @@ _SIGS = {
     'vc_highway_backward': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     'vc_col_sum': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
     'vc_fill': (C.c_int, [_P, C.c_float, C.c_size_t, _P]),
+    'vc_axpby': (C.c_int, [_P, C.c_int32, C.c_float, _P, C.c_int32, C.c_float, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     'vc_mse_loss': (C.c_int, [_P, _P, C.c_size_t, C.c_float, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     'vc_softmax_ce': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),
     'vc_adam_step': (C.c_int, [_P, _P, _P, _P, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float,

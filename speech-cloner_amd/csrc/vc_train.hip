@@ -196,6 +196,20 @@ fill_kernel(float* p, float v, size_t n) {
     for (; i < n; i += stride) p[i] = v;
 }
 
+// out[m][c] = a * X[m][c] + b * Y[m][c] on [M, C] views with row strides (teacher-forced blend of decoder stage 2's
+// input, /root/reference/decoder.py:152, and its gradient)
+__global__ void __launch_bounds__(TB)
+axpby_kernel(const float* X, int ldx, float a, const float* Y, int ldy, float b, float* out, int ldo, int M, int C) {
+    const size_t n = (size_t)M * C;
+    size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * TB;
+    for (; i < n; i += stride) {
+        const size_t r = i / C;
+        const int c = (int)(i - r * C);
+        out[r * ldo + c] = a * X[r * ldx + c] + b * Y[r * ldy + c];
+    }
+}
+
 // ---------------------------------------------------------------------------- transpose (+prologue)
 // X [M, C] (ld) -> XT [C, ldt] at column offset `pad`:  XT[c][pad + m] = pro(X)[m][c]
 //   pro: optional per-channel affine, relu, time max-pool (same rule as the forward operand load),
@@ -859,6 +873,16 @@ int vc_col_sum(const float* d_X, int32_t M, int32_t C, int32_t ld, float* d_out,
 int vc_fill(float* d_p, float value, size_t n, void* stream) {
     VC_REQUIRE(d_p, "NULL argument");
     if (n) hipLaunchKernelGGL(fill_kernel, dim3(nblocks(n)), dim3(TB), 0, static_cast<hipStream_t>(stream), d_p, value, n);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_axpby(const float* d_X, int32_t ldx, float a, const float* d_Y, int32_t ldy, float b, float* d_out, int32_t ldo,
+             int32_t M, int32_t C, void* stream) {
+    VC_REQUIRE(d_X && d_Y && d_out, "NULL argument");
+    VC_REQUIRE(M > 0 && C > 0 && ldx >= C && ldy >= C && ldo >= C, "bad shape M=%d C=%d ld=%d/%d/%d", M, C, ldx, ldy, ldo);
+    hipLaunchKernelGGL(axpby_kernel, dim3(nblocks((size_t)M * C)), dim3(TB), 0, static_cast<hipStream_t>(stream), d_X, ldx, a,
+                       d_Y, ldy, b, d_out, ldo, M, C);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }

@@ -70,9 +70,6 @@ class decoder_specs:
         self._scope = scope
         if c['use_lstm']:
             raise NotImplementedError(' - ERROR, use_lstm is not supported (no shipped configuration uses it)')
-        if c.get('use_target_mel_step2', False):
-            raise NotImplementedError(' - ERROR, use_target_mel_step2 (teacher-forced step 2, decoder.py:148-152) is off '
-                                      'in every shipped configuration and not built')
         T, n_in = c['input_shape']
         if self.encoder is None:
             self.inputs = Handle(scope + '/inputs', (None, T, n_in))
@@ -92,6 +89,13 @@ class decoder_specs:
                                            sd['num_conv_banks'], sd['num_highwaynet_blocks'], sd['n_output'])
             cin = sd['n_output']
             prev_E = E
+        # decoder.py:148-152: teacher-forced stage 2 -- inputs_step2 = f * y_mel + (1 - f) * target_mel with the
+        # non-trainable scalar decoder/step2/inputs_step2/f_mel_pred_tf (0.0 at first, raised per epoch, :258-260)
+        self._F_NAME = '{}/step2/inputs_step2/f_mel_pred_tf'.format(scope)
+        self.f_mel_pred = 0.0
+        if c.get('use_target_mel_step2', False):
+            self.store.get(self._F_NAME, (), 0.0)
+            self.store.non_trainable.add(self._F_NAME)
         n_mel, n_stft = c['steps_v'][0]['n_output'], c['steps_v'][1]['n_output']
         self.y_mel = Handle(scope + '/y_mel', (None, T, n_mel))
         self.target_mel = Handle(scope + '/step1/target', (None, T, n_mel))
@@ -112,12 +116,17 @@ class decoder_specs:
             raise ValueError(' - ERROR, {} must be [N, {}, {}], got {}'.format(what, T, width, tuple(x.shape)))
         return x.contiguous()
 
-    def forward_from_ppg(self, ppg):
+    def forward_from_ppg(self, ppg, target_mel=None):
         """Stages step1/step2 on device posteriors ``ppg`` [N, T, pad8(n_in)] (compute dtype, zero
-        padding columns).  Returns (y_mel f32, y_stft f32)."""
+        padding columns).  Returns (y_mel f32, y_stft f32).  With use_target_mel_step2 the second stage is fed
+        f_mel_pred * y_mel + (1 - f_mel_pred) * target_mel (decoder.py:152) and ``target_mel`` is required -- like
+        the reference's graph, which cannot be evaluated without that placeholder."""
         c = self.cfg_d
         if c['is_training']:
             raise NotImplementedError(' - ERROR, use exec_train_step for training mode')
+        blend = c.get('use_target_mel_step2', False)
+        if blend and target_mel is None:
+            raise Exception(' - ERROR, use_target_mel_step2: the second stage needs target_mel (feed decoder.target_mel)')
         st = self.store
         x = ppg
         cin = c['input_shape'][-1]
@@ -135,9 +144,12 @@ class decoder_specs:
                 cin = sd['n_output']
                 if i + 1 < len(c['steps_v'][:2]):
                     x = y                                       # step2's input is y_mel (decoder.py:155); prenet converts on load
+                    if blend:
+                        f = float(self.f_mel_pred)
+                        x = modules.axpby(y, f, target_mel, 1.0 - f)
         return ys[0], ys[1]
 
-    def forward(self, x):
+    def forward(self, x, target_mel=None):
         """x: encoder features [N, T, n_feat] (or posteriors [N, T, n_in] when there is no
         encoder).  Returns dict(y_mel, y_stft, y_phn) of float32 device tensors."""
         import torch
@@ -151,7 +163,7 @@ class decoder_specs:
             ppg = torch.zeros((x.shape[0], x.shape[1], pad), dtype=torch.float32, device=x.device)
             ppg[:, :, :n_in] = x
             ppg = modules.convert(ppg, self.store.dtype)
-        y_mel, y_stft = self.forward_from_ppg(ppg)
+        y_mel, y_stft = self.forward_from_ppg(ppg, target_mel)
         return {'y_mel': y_mel, 'y_stft': y_stft, 'y_phn': y_phn, 'dec_inputs': y_phn}
 
     # --------------------------------------------------------------------------- checkpoints
@@ -197,6 +209,8 @@ class decoder_specs:
                     self.opt_state[k] = w[k]
             self.i_global_step = int(self.opt_state['dec_opt/global_step'])
             self.i_epoch = int(self.opt_state['dec_opt/epoch'])
+            if self._F_NAME in self.store.vars:
+                self.f_mel_pred = float(self.store.vars[self._F_NAME])
             if self.cfg_d['is_training']:
                 # tf.train.Saver restores the Adam slots (dec_opt/<var>/Adam, Adam_1) and the step with the weights:
                 # an existing trainer takes them now, a later one when it is created (_get_trainer)
@@ -221,6 +235,9 @@ class decoder_specs:
         one chunk's latency-bound recurrences overlap with another chunk's GEMMs (results are
         identical to the sequential order)."""
         import torch
+        if self.cfg_d.get('use_target_mel_step2', False):
+            raise Exception(' - ERROR, predict: a model built with use_target_mel_step2 needs target_mel for its second '
+                            'stage (decoder.py:152); evaluate it through run() / exec_calc_metrics')
         n_chunks = (x.shape[0] + batch_size - 1) // batch_size
         use_streams = n_streams > 1 and n_chunks > 1 and torch.cuda.is_available()
         if use_streams and len(getattr(self, '_streams', None) or ()) != n_streams:
@@ -270,7 +287,10 @@ class decoder_specs:
         vs = [var] if single else list(var)
         if self.inputs not in feed_dict:
             raise Exception(' - ERROR, run: feed_dict must provide decoder.inputs')
-        o = self.forward(self._to_device(feed_dict[self.inputs], self._input_width(), 'decoder input'))
+        tm = None
+        if self.cfg_d.get('use_target_mel_step2', False) and self.target_mel in feed_dict:
+            tm = self._to_device(feed_dict[self.target_mel], self.cfg_d['steps_v'][0]['n_output'], 'target_mel')
+        o = self.forward(self._to_device(feed_dict[self.inputs], self._input_width(), 'decoder input'), tm)
         losses = None
         res = []
         for v in vs:
@@ -294,7 +314,10 @@ class decoder_specs:
         """decoder.py:349-376 without the TensorBoard writers: (mel_loss, stft_loss, loss)."""
         if summary_mode not in ('train', 'validation', 'test'):
             raise Exception(' - ERROR, summary_mode={} not implemented'.format(summary_mode))
-        o = self.forward(self._to_device(inputs, self._input_width(), 'decoder input'))
+        tm = None
+        if self.cfg_d.get('use_target_mel_step2', False):
+            tm = self._to_device(target_mel, self.cfg_d['steps_v'][0]['n_output'], 'target_mel')
+        o = self.forward(self._to_device(inputs, self._input_width(), 'decoder input'), tm)
         return self._losses(o, target_mel, target_stft)
 
     def eval_loss(self, ds_sampler, n_batchs=100):
@@ -343,6 +366,19 @@ class decoder_specs:
         self.i_global_step = global_step
         return (mel_loss, stft_loss, loss, np.int32(global_step), None)
 
+    def _set_f_mel_pred(self, value):
+        self.f_mel_pred = float(value)
+        if self._F_NAME in self.store.vars:
+            self.store.vars[self._F_NAME].fill_(float(value))
+
+    def _f_mel_pred_update(self):
+        """decoder.py:258-260: f_mel_pred = min(1, 1.02 * tanh(epoch / target_mel_step2_val)) -- float32 like the
+        graph's ops."""
+        e = np.float32(int(self.opt_state['dec_opt/epoch']))
+        f = np.minimum(np.float32(1.0), np.float32(1.02) * np.tanh(e / np.float32(self.cfg_d['target_mel_step2_val'])))
+        self._set_f_mel_pred(np.float32(f))
+        return self.f_mel_pred
+
     def _lr_decay(self):
         """decoder.py:248: lr = lr_start / (1 + decay * epoch)."""
         o = self.opt_state
@@ -380,10 +416,17 @@ class decoder_specs:
             if (global_step / self.cfg_d['n_steps_epoch_trn']) % self.cfg_d['save_each_n_epochs'] == 0:
                 print(' Saving, epoch={} ...'.format(self.i_epoch))
                 self.save()
+                mfcc_val, mel_val, stft_val = next(self.iter_val)
+                mel_loss_val, stft_loss_val, loss_val = self.exec_calc_metrics(mfcc_val, mel_val, stft_val)
+                print(' - i_epoch={}   global_step={}   mel_loss_val={:6.3f}   stft_loss_val={:6.3f}   loss_val={:6.3f}'.format(
+                    self.i_epoch, int(global_step), mel_loss_val, stft_loss_val, loss_val))
             if global_step % self.cfg_d['n_steps_epoch_trn'] == 0:
                 self.opt_state['dec_opt/epoch'] = np.int32(int(self.opt_state['dec_opt/epoch']) + 1)
                 self.i_epoch = int(self.opt_state['dec_opt/epoch'])
                 self.lr = self._lr_decay()
+                if self.cfg_d.get('use_target_mel_step2', False):
+                    self._f_mel_pred_update()
+                    print(' - New epoch, f_mel_pred = {0:02f}'.format(self.f_mel_pred))
                 if self.i_epoch >= self.cfg_d['n_epochs']:
                     break
         print(' End of Training !!!')

@@ -247,6 +247,20 @@ def convert(x, dtype):
     return y
 
 
+def axpby(x, a, y, b, out=None):
+    """out = a * x + b * y on float32 [N, T, C] tensors (vc_axpby; out may be x or y)."""
+    torch = _torch()
+    if x.dtype != torch.float32 or y.dtype != torch.float32 or x.shape != y.shape:
+        raise ValueError(' - ERROR, axpby wants two float32 tensors of one shape')
+    x, y = x.contiguous(), y.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    Cn = x.shape[-1]
+    _vc.check(_vc.lib().vc_axpby(x.data_ptr(), Cn, float(a), y.data_ptr(), Cn, float(b), out.data_ptr(), Cn,
+                                 x.numel() // Cn, Cn, _vc.current_stream()))
+    return out
+
+
 # ------------------------------------------------------------------------------- weight prep
 def _prep_dense(store, scope, cin, units, bias_init=0.0):
     k = store.get(scope + '/kernel', (cin, units), 'glorot')
@@ -321,6 +335,23 @@ def _prep_gru(store, scope, cin, H):
         wh = [torch.cat([w[d][0][cin:], w[d][2][cin:]], 1).contiguous().to(store.dtype) for d in ('fw', 'bw')]
         return btx.contiguous().to(store.dtype), bx.contiguous(), wh[0], wh[1]
     return store.cached(('gru', scope), build)
+
+
+def _prep_gru_uni(store, scope, cin, H):
+    """Kernel-format weights of a unidirectional GRU (tf.nn.dynamic_rnn default scope 'rnn')."""
+    s = '{}/rnn/gru_cell'.format(scope)
+    wg = store.get(s + '/gates/kernel', (cin + H, 2 * H), 'glorot')
+    bg = store.get(s + '/gates/bias', (2 * H,), 1.0)
+    wc = store.get(s + '/candidate/kernel', (cin + H, H), 'glorot')
+    bc = store.get(s + '/candidate/bias', (H,), 0.0)
+
+    def build():
+        torch = _torch()
+        one = torch.cat([wg[:cin].t(), wc[:cin].t()], 0)
+        b1 = torch.cat([bg, bc], 0)
+        wh = torch.cat([wg[cin:], wc[cin:]], 1).contiguous().to(store.dtype)
+        return torch.cat([one, one], 0).contiguous().to(store.dtype), torch.cat([b1, b1], 0).contiguous(), wh
+    return store.cached(('gru_uni', scope), build)
 
 
 # ------------------------------------------------------------------------------- blocks
@@ -432,15 +463,22 @@ def conv1d_banks(inputs, K=16, embed_size=256, is_training=True, scope="conv1d_b
 
 
 def gru(inputs, num_units=None, bidirection=False, scope="gru", use_Cudnn=False, reuse=None):
-    """modules.py:168-204 with bidirection=True (the only form CBHG uses): the x-halves of both
-    directions' cell matmuls are one GEMM, the recurrence one persistent launch."""
-    if not bidirection:
-        raise NotImplementedError(' - ERROR, gru: the reference only instantiates the bidirectional form')
+    """modules.py:168-204: the x-halves of both directions' cell matmuls are one GEMM, the recurrence one
+    persistent launch (bidirection=True is the only form CBHG uses; the unidirectional form is provided too)."""
     torch = _torch()
     store = _store()
     x = _as3(inputs)
     N_, T_, Cin = x.shape
     H = Cin if num_units is None else num_units
+    if not bidirection:
+        # modules.py:202-204: tf.nn.dynamic_rnn over one GRUCell (variables <scope>/rnn/gru_cell/...).  No shipped
+        # configuration builds it (CBHG asks for the bidirectional form), so it rides on the bidirectional launch with
+        # the forward cell in both slots; the second half of the result is dropped.
+        btx, bx, wh = _prep_gru_uni(store, _scope(scope), Cin, H)
+        xproj = torch.empty((N_ * T_, 6 * H), dtype=torch.float32, device=x.device)
+        gemm_launch(x, N_ * T_, T_, Cin, Cin, 6 * H, [(btx, Cin, 1, 0, 0)], xproj, 6 * H, store.vc_dtype,
+                    epi_shift=bx, out_f32=True)
+        return _gru_recurrence(xproj, N_, T_, H, wh, wh)[:, :, :H].contiguous()
     btx, bx, wh_fw, wh_bw = _prep_gru(store, _scope(scope), Cin, H)
     xproj = torch.empty((N_ * T_, 6 * H), dtype=torch.float32, device=x.device)
     gemm_launch(x, N_ * T_, T_, Cin, Cin, 6 * H, [(btx, Cin, 1, 0, 0)], xproj, 6 * H, store.vc_dtype,

@@ -496,6 +496,12 @@ class DecoderTrainer(StageTrainer):
                                           sd1['n_output'], seed)
             n1 = sd1['n_output']
             x2 = y1.view(ppg.shape[0], ppg.shape[1], y1.shape[1])
+            f_mel = 1.0
+            if c.get('use_target_mel_step2', False):          # decoder.py:152: teacher-forced stage-2 input
+                f_mel = float(dec.f_mel_pred)
+                ld1 = y1.shape[1]
+                x2 = torch.zeros_like(x2) if ld1 != n1 else torch.empty_like(x2)
+                _vc.check(_lib().vc_axpby(_p(y1), ld1, f_mel, _p(target_mel), n1, 1.0 - f_mel, _p(x2), ld1, M, n1, _st()))
             y2, sv2 = self._stage_forward(s2, x2, n1, dec._E[1], sd2['num_conv_banks'], sd2['num_highwaynet_blocks'],
                                           sd2['n_output'], seed + 10)
             n2 = sd2['n_output']
@@ -515,7 +521,9 @@ class DecoderTrainer(StageTrainer):
                 dY2.mul_(1.0 / ls)
             dX2 = self._stage_backward(s2, sv2, dY2, need_dx=True)
             del sv2
-            dY1.add_(dX2)                         # y_mel feeds step 2 (decoder.py:155)
+            # y_mel feeds step 2 (decoder.py:155; through the blend with weight f_mel_pred when teacher-forced, :152)
+            _vc.check(_lib().vc_axpby(_p(dY1), dY1.shape[1], 1.0, _p(dX2), dX2.shape[1], f_mel, _p(dY1), dY1.shape[1], M,
+                                      dY1.shape[1], _st()))
             self._stage_backward(s1, sv1, dY1, need_dx=False)
         return self.losses
 

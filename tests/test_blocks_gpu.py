@@ -243,6 +243,22 @@ def test_gru_bidirectional(dtype, H, T):
     _close(y, ref, 5e-5 if dtype == 'float32' else 3e-2, 'gru H=%d' % H)
 
 
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_gru_unidirectional(dtype):
+    """modules.py:202-204: gru(bidirection=False) = tf.nn.dynamic_rnn over one GRUCell, variables <scope>/rnn/gru_cell."""
+    import modules
+    rng = np.random.RandomState(17)
+    N, T, H = 3, 50, 40
+    st = _store(dtype)
+    x = torch.from_numpy((0.7 * rng.standard_normal((N, T, H))).astype(np.float32))
+    with modules.variable_store(st), modules.variable_scope('g'):
+        y = modules.gru(modules.convert(x.cuda(), st.dtype), num_units=H, bidirection=False)
+    assert y.shape == (N, T, H) and 'g/gru/rnn/gru_cell/gates/kernel' in st.vars
+    cast = (lambda t: t.double()) if dtype == 'float32' else (lambda t: t.float().bfloat16().double())
+    w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
+    _close(y, mo.gru_direction(cast(x), w, 'g/gru/rnn'), 5e-5 if dtype == 'float32' else 3e-2, 'gru unidirectional')
+
+
 @pytest.mark.parametrize('N,T,cin,K', [(3, 100, 128, 32), (2, 400, 64, 4), (4, 255, 64, 2), (7, 64, 128, 6)])
 def test_conv1d_banks_pooled_output(N, T, cin, K):
     """epi_pool: the bank launch stores max_pooling1d(2, 1, 'same') of its result (modules.py:331);

@@ -51,7 +51,7 @@ def _setup(cfg, N=4, seed=3):
     return dec, w, ppg, t_mel, t_stft
 
 
-def _oracle_step(cfg, w, ppg, t_mel, t_stft, seed_base, taps=None):
+def _oracle_step(cfg, w, ppg, t_mel, t_stft, seed_base, taps=None, f_mel_pred=None):
     N, T = ppg.shape[:2]
     M = N * T
     keep = 1.0 - cfg['dropout_rate']
@@ -67,7 +67,7 @@ def _oracle_step(cfg, w, ppg, t_mel, t_stft, seed_base, taps=None):
     wt = mo.to_torch(w, torch.float64, requires_grad=True)
     stats = {}
     ym, ys = mo.decoder_forward(torch.from_numpy(ppg).double(), wt, cfg, is_training=True, masks=masks, stats_out=stats,
-                                taps=taps)
+                                taps=taps, target_mel=torch.from_numpy(t_mel).double(), f_mel_pred=f_mel_pred)
     ml, sl, loss = mo.decoder_loss(ym, ys, torch.from_numpy(t_mel).double(), torch.from_numpy(t_stft).double(), cfg)
     loss.backward()
     grads = {k: v.grad.numpy() for k, v in wt.items() if v.requires_grad}
@@ -99,6 +99,68 @@ def test_train_step_gradients_match_autograd(dropout, loss_type):
     # moving statistics were updated in place with the Bessel-corrected batch variance
     for n, v in stats.items():
         assert np.abs(dec.store.vars[n].cpu().numpy() - v.numpy()).max() < 1e-5, n
+
+
+def test_teacher_forced_stage2_matches_autograd(tmp_path):
+    """use_target_mel_step2 (/root/reference/decoder.py:148-152, 258-260, 435-437): stage 2 is fed
+    f_mel_pred * y_mel + (1 - f_mel_pred) * target_mel; f_mel_pred is a saved, non-trainable scalar raised per epoch
+    as min(1, 1.02 tanh(epoch / target_mel_step2_val)).  Training forward / backward against autograd on the oracle at
+    f = 0.3 (the gradient reaches y_mel through the blend with weight f), the inference graph through
+    exec_calc_metrics, the schedule, the checkpoint variable."""
+    import tf_bundle
+    from decoder import decoder_specs
+    cfg = _cfg()
+    cfg.update(use_target_mel_step2=True, target_mel_step2_val=500, model_path=str(tmp_path))
+    dec = decoder_specs(cfg, None, None)
+    fname = 'decoder/step2/inputs_step2/f_mel_pred_tf'
+    assert fname in dec.store.vars and fname not in dec.store.trainable_names('decoder/')
+    w = mo.init_weights(cfg, 'decoder', seed=5, perturb_bn=True)
+    dec.store.load_dict(w, strict=False)
+    rng = np.random.RandomState(3)
+    ppg = torch.softmax(torch.from_numpy(rng.standard_normal((4, 40, 61)) * 2), -1).float().numpy()
+    t_mel = rng.uniform(0, 0.8, (4, 40, 80)).astype(np.float32)
+    t_stft = rng.uniform(0, 0.8, (4, 40, 201)).astype(np.float32)
+    dec._set_f_mel_pred(0.3)
+    tr = dec._get_trainer()
+    losses = tr.forward_backward(*(torch.from_numpy(a).cuda() for a in (ppg, t_mel, t_stft))).cpu().numpy()
+    ml, sl, grads, stats, ym, ys = _oracle_step(cfg, w, ppg, t_mel, t_stft, tr.seed, f_mel_pred=0.3)
+    assert abs(losses[0] - ml) < 1e-5 * max(1, ml) and abs(losses[1] - sl) < 1e-5 * max(1, sl), (losses, ml, sl)
+    assert np.abs(tr.y_stft.cpu().numpy().reshape(ys.shape) - ys).max() < 1e-4
+    worst = ('', 0.0)
+    for n in tr.names:
+        err = np.abs(tr.g(n).cpu().numpy() - grads[n]).max() / max(np.abs(grads[n]).max(), 1e-6)
+        if err > worst[1]:
+            worst = (n, err)
+    assert worst[1] < 2e-3, 'worst gradient mismatch %s: %.3e' % worst
+    # f = 0: stage 1 gets no gradient from the stft loss at all (its input is the target alone)
+    dec._set_f_mel_pred(0.0)
+    tr.forward_backward(*(torch.from_numpy(a).cuda() for a in (ppg, t_mel, t_stft)))
+    _, _, g0, _, _, _ = _oracle_step(cfg, w, ppg, t_mel, t_stft, tr.seed, f_mel_pred=0.0)
+    n1 = 'decoder/step1/y_logits/kernel'
+    assert np.abs(tr.g(n1).cpu().numpy() - g0[n1]).max() < 2e-3 * np.abs(g0[n1]).max()
+    # the schedule (float32 ops of the graph) and the checkpoint
+    dec.opt_state['dec_opt/epoch'] = np.int32(250)
+    f = dec._f_mel_pred_update()
+    assert abs(f - min(1.0, 1.02 * np.tanh(250 / 500.0))) < 1e-6 and abs(float(dec.store.vars[fname]) - f) < 1e-7
+    dec.opt_state['dec_opt/epoch'] = np.int32(5000)
+    assert dec._f_mel_pred_update() == 1.0
+    dec._set_f_mel_pred(0.3)
+    dec.save(verbose=False)
+    ck = tf_bundle.read_bundle(tf_bundle.latest_checkpoint(str(tmp_path)))
+    assert abs(float(ck[fname]) - 0.3) < 1e-7
+    # inference graph of the same configuration: needs target_mel (like the reference's placeholder), predict refuses
+    icfg = dict(cfg, is_training=False)
+    idec = decoder_specs(icfg, None, None)
+    idec.restore()
+    assert abs(idec.f_mel_pred - 0.3) < 1e-7
+    got = idec.exec_calc_metrics(ppg, t_mel, t_stft)
+    wi = {k: v for k, v in ck.items() if k in w}
+    ym_i, ys_i = mo.decoder_forward(torch.from_numpy(ppg).double(), mo.to_torch(wi, torch.float64), icfg,
+                                    target_mel=torch.from_numpy(t_mel).double(), f_mel_pred=0.3)
+    mli, sli, _ = mo.decoder_loss(ym_i, ys_i, torch.from_numpy(t_mel).double(), torch.from_numpy(t_stft).double(), icfg)
+    assert abs(got[0] - float(mli)) < 1e-4 * max(1, float(mli)) and abs(got[1] - float(sli)) < 1e-4 * max(1, float(sli))
+    with pytest.raises(Exception, match='use_target_mel_step2'):
+        idec.predict(ppg)
 
 
 def test_adam_update_and_second_step():
