@@ -223,6 +223,14 @@ int vc_conv_gemm(const vc_gemm_desc* desc, void* stream);
  * maps onto the paired 256-row tiles (tiles then overlap by one frame), else 0.  Host-only. */
 int vc_conv_gemm_epi_pool_supported(const vc_gemm_desc* desc);
 
+/* Bidirectional LSTM recurrence: modules.lstm (/root/reference/modules.py:207-243 -> tf.contrib.rnn.LSTMCell with its
+ * defaults: no peepholes, no projection, forget_bias 1.0, gate order i, j, f, o; bidirectional_dynamic_rnn, zero state).
+ * d_xproj [n_seq*T, 8H] float32 = x W_x + b for both directions (fw | bw, 4H columns each); d_Wh_* [H, 4H] recurrent
+ * halves (w_dtype); d_out [n_seq, T, 2H] (fw | bw).  H <= 512.  Reachable only with use_lstm = true, which no shipped
+ * configuration sets: an any-size kernel, not a tuned one. */
+int vc_lstm_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw, int32_t w_dtype, int32_t n_seq, int32_t T,
+                  int32_t H, void* d_out, int32_t out_dtype, void* stream);
+
 /* softmax + argmax over the last axis (encoder.py:110-111): logits float32 [M, ldl >= N] ->
  * probabilities (dtype out_dtype, row stride ldp, columns [N, ldp) zero-filled so the
  * decoder's first dense can read 16-byte rows) and int32 class ids (first maximum). */

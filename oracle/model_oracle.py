@@ -160,6 +160,33 @@ def gru_bidirectional(x, w, scope):
     return torch.cat([fw, bw], dim=2)
 
 
+def lstm_direction(x, w, scope, reverse=False):
+    """One tf.nn.dynamic_rnn over tf.contrib.rnn.LSTMCell(H) with its TF-1.9 defaults (modules.py:236-243):
+    no peepholes, no projection, forget_bias = 1.0, state zero; lstm_matrix = [x, h] W + b,
+    i, j, f, o = split(lstm_matrix, 4); c' = sigmoid(f + 1) c + sigmoid(i) tanh(j); h' = sigmoid(o) tanh(c').
+    **Parity unpinned**: recalled from TensorFlow's published rnn_cell_impl.LSTMCell (third-party, absent from the
+    reference); no artefact of the reference contains an LSTM graph (its saved graph uses GRU cells)."""
+    W, b = w[scope + '/lstm_cell/kernel'], w[scope + '/lstm_cell/bias']
+    N, T, C = x.shape
+    H = W.shape[1] // 4
+    h = x.new_zeros((N, H))
+    c = x.new_zeros((N, H))
+    outs = [None] * T
+    for t in (range(T - 1, -1, -1) if reverse else range(T)):
+        z = torch.cat([x[:, t], h], dim=1) @ W + b
+        i, j, f, o = z[:, :H], z[:, H:2 * H], z[:, 2 * H:3 * H], z[:, 3 * H:]
+        c = torch.sigmoid(f + 1.0) * c + torch.sigmoid(i) * torch.tanh(j)
+        h = torch.sigmoid(o) * torch.tanh(c)
+        outs[t] = h
+    return torch.stack(outs, dim=1)
+
+
+def lstm_bidirectional(x, w, scope):
+    fw = lstm_direction(x, w, scope + '/bidirectional_rnn/fw', reverse=False)
+    bw = lstm_direction(x, w, scope + '/bidirectional_rnn/bw', reverse=True)
+    return torch.cat([fw, bw], dim=2)
+
+
 def cbhg(x, w, scope, K, n_highway, is_training=False, stats_out=None, taps=None):
     """modules.py:323-356.  ``taps``: optional dict that receives intermediate tensors."""
     y = conv1d_banks(x, w, scope + '/conv1d_banks', K, is_training, stats_out, taps=taps)
@@ -179,6 +206,8 @@ def cbhg(x, w, scope, K, n_highway, is_training=False, stats_out=None, taps=None
         y = highwaynet(y, w, scope + '/highwaynet_%d' % i)
     if taps is not None:
         taps['highway'] = y
+    if (scope + '/lstm/bidirectional_rnn/fw/lstm_cell/kernel') in w:          # use_lstm (modules.py:347-350)
+        return lstm_bidirectional(y, w, scope + '/lstm')
     y = gru_bidirectional(y, w, scope + '/gru')
     return y
 

@@ -119,6 +119,7 @@ _SIGS = {
     'vc_gru_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32]),
     'vc_gru_bidir': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P,
                                C.c_size_t, _P]),
+    'vc_lstm_bidir': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     'vc_convert': (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_size_t, _P]),
     'vc_conv_wgrad': (C.c_int, [C.POINTER(WgradDesc), _P]),
     'vc_transpose_pad': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32,

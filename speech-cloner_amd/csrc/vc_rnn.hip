@@ -117,6 +117,63 @@ gru_generic_kernel(GruArgs a) {
 
 
 // ------------------------------------------------------------------------------------------
+// LSTM recurrence (modules.py:207-243 -> tf.contrib.rnn.LSTMCell, no peepholes, no projection, forget_bias 1.0):
+//   z = [x, h] W + b;  i, j, f, o = split(z, 4);  c' = sigmoid(f + 1) c + sigmoid(i) tanh(j);  h' = sigmoid(o) tanh(c')
+// xproj [n_seq*T, 8H] float32 holds x W_x + b of both directions (fw | bw, 4H each); Wh[dir] is the recurrent half
+// [H, 4H].  One workgroup per (sequence, direction); a thread owns gate columns tid, tid + NT, ...  No shipped
+// configuration enables use_lstm: a plain, any-H kernel (weights from LDS when they fit, else L2), not a tuned one.
+struct LstmArgs {
+    const float* xproj;
+    const void* Wh[2];
+    int32_t n_seq, T, H;
+    void* out;
+    int32_t out_bf16, w_in_lds;
+};
+
+template <typename WT>
+__global__ void __launch_bounds__(512)
+lstm_generic_kernel(LstmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.H, H4 = 4 * H, NT = blockDim.x, tid = threadIdx.x;
+    float* h = reinterpret_cast<float*>(smem);      // [H]
+    float* z = h + H;                               // [4H]
+    WT* wl = reinterpret_cast<WT*>(z + H4);         // [H][4H] when cached
+    const int seq = blockIdx.x, dir = blockIdx.y;
+    const WT* W = reinterpret_cast<const WT*>(a.Wh[dir]);
+    if (a.w_in_lds) {
+        for (int i = tid; i < H * H4; i += NT) wl[i] = W[i];
+        W = wl;
+    }
+    for (int i = tid; i < H; i += NT) h[i] = 0.0f;
+    float c = 0.0f;                                 // cell state of unit tid (threads tid < H; H <= NT asserted by the host)
+    const size_t xrow = 8 * (size_t)H;
+    const float* xbase = a.xproj + (size_t)seq * a.T * xrow + (size_t)dir * H4;
+    __syncthreads();
+    int t = dir ? a.T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    for (int step = 0; step < a.T; ++step, t += dt) {
+        const float* xr = xbase + (size_t)t * xrow;
+        for (int col = tid; col < H4; col += NT) {
+            float acc = xr[col];
+            const WT* w = W + col;
+#pragma unroll 4
+            for (int k = 0; k < H; ++k) acc = fmaf(h[k], ld_w(w + (size_t)k * H4), acc);
+            z[col] = acc;
+        }
+        __syncthreads();
+        if (tid < H) {
+            const float gi = sigmoidf_(z[tid]), gj = tanhf(z[H + tid]);
+            const float gf = sigmoidf_(z[2 * H + tid] + 1.0f), go = sigmoidf_(z[3 * H + tid]);
+            c = gf * c + gi * gj;
+            const float hn = go * tanhf(c);
+            h[tid] = hn;
+            st_out<WT>(a.out, ((size_t)seq * a.T + t) * 2 * H + (size_t)dir * H + tid, hn, a.out_bf16);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Register-resident recurrence (H = 128 or 256): NT threads hold the WHOLE recurrent matrix
 // [H, 3H] in VGPRs for all T steps (bf16 at H = 256: 3H^2*2 B = 393 KB of the CU's 512 KB register
 // file = 192 VGPRs per lane at NT = 512, two waves per SIMD; H = 128: NT = 1024, 24 (bf16) or 48
@@ -672,6 +729,32 @@ int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw,
         VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_generic_kernel<__bf16>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(gru_generic_kernel<__bf16>, grid, dim3(nt), lds, st, a);
+    }
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_lstm_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw, int32_t w_dtype, int32_t n_seq, int32_t T,
+                  int32_t H, void* d_out, int32_t out_dtype, void* stream) {
+    VC_REQUIRE(d_xproj && d_Wh_fw && d_Wh_bw && d_out, "NULL argument");
+    VC_REQUIRE(n_seq > 0 && T > 0 && H > 0 && H <= 512 && n_seq <= 65535, "vc_lstm_bidir: bad shape n_seq=%d T=%d H=%d (H <= 512)", n_seq, T, H);
+    VC_REQUIRE((w_dtype == VC_F32 || w_dtype == VC_BF16) && (out_dtype == VC_F32 || out_dtype == VC_BF16), "bad dtype");
+    LstmArgs a;
+    a.xproj = d_xproj; a.Wh[0] = d_Wh_fw; a.Wh[1] = d_Wh_bw; a.n_seq = n_seq; a.T = T; a.H = H;
+    a.out = d_out; a.out_bf16 = out_dtype == VC_BF16;
+    const size_t base = (size_t)5 * H * sizeof(float);
+    const size_t wbytes = (size_t)4 * H * H * (w_dtype == VC_F32 ? 4 : 2);
+    a.w_in_lds = (base + wbytes <= 150 * 1024);
+    const size_t lds = base + (a.w_in_lds ? wbytes : 0);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (w_dtype == VC_F32) {
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_generic_kernel<float>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(lstm_generic_kernel<float>, dim3(n_seq, 2), dim3(512), lds, st, a);
+    } else {
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lstm_generic_kernel<__bf16>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(lstm_generic_kernel<__bf16>, dim3(n_seq, 2), dim3(512), lds, st, a);
     }
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;

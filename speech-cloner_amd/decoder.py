@@ -68,8 +68,8 @@ class decoder_specs:
         c = self.cfg_d
         scope = c['model_name']
         self._scope = scope
-        if c['use_lstm']:
-            raise NotImplementedError(' - ERROR, use_lstm is not supported (no shipped configuration uses it)')
+        if c['use_lstm'] and c['is_training']:
+            raise NotImplementedError(' - ERROR, use_lstm is built for inference only (no shipped configuration uses it)')
         T, n_in = c['input_shape']
         if self.encoder is None:
             self.inputs = Handle(scope + '/inputs', (None, T, n_in))
@@ -86,7 +86,8 @@ class decoder_specs:
             E = self._step_embed(i, prev_E)
             self._E.append(E)
             modules.create_stage_variables(self.store, '{}/step{}'.format(scope, i + 1), cin, E,
-                                           sd['num_conv_banks'], sd['num_highwaynet_blocks'], sd['n_output'])
+                                           sd['num_conv_banks'], sd['num_highwaynet_blocks'], sd['n_output'],
+                                           use_lstm=c['use_lstm'])
             cin = sd['n_output']
             prev_E = E
         # decoder.py:148-152: teacher-forced stage 2 -- inputs_step2 = f * y_mel + (1 - f) * target_mel with the

@@ -76,12 +76,12 @@ class encoder_spec_phn:
         """encoder.py:78-123: creates the variables (TF names) and the attribute handles."""
         if embed_size is None:
             embed_size = input_shape[-1]
-        if use_lstm:
-            raise NotImplementedError(' - ERROR, use_lstm is not supported (no shipped configuration uses it)')
+        if use_lstm and is_training:
+            raise NotImplementedError(' - ERROR, use_lstm is built for inference only (no shipped configuration uses it)')
         self._embed_size = embed_size
         self._scope = scope
         modules.create_stage_variables(self.store, scope, input_shape[-1], embed_size, num_conv_banks,
-                                       num_highwaynet_blocks, n_output)
+                                       num_highwaynet_blocks, n_output, use_lstm=use_lstm)
         T = input_shape[0]
         self.inputs = Handle(scope + '/inputs', (None,) + tuple(input_shape))
         self.target = Handle(scope + '/target', (None, T, n_output))
@@ -119,6 +119,9 @@ class encoder_spec_phn:
             raise Exception(' - ERROR, forward() is the inference graph; a model built with is_training=True '
                             'is evaluated through exec_train_step / exec_calc_metrics')
         st = self.store
+        if x.dtype != torch.float32 or not x.is_cuda:
+            raise ValueError(' - ERROR, encoder.forward wants a float32 device tensor, got {} on {} '
+                             '(predict() / run() convert host arrays)'.format(x.dtype, x.device))
         with modules.variable_store(st), modules.variable_scope(self._scope):
             cbhg_out = modules.prenet_CBHG(x, self._embed_size, c['num_conv_banks'], c['num_highwaynet_blocks'],
                                            c['dropout_rate'], False, prenet_scope="prenet", scope="CBHG",

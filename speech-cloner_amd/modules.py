@@ -14,7 +14,8 @@ and cached; ``VariableStore.invalidate()`` drops them after a weight update.
 
 ``embed`` and ``attention_decoder`` (modules.py:10-36, 246-272) are dead code in the reference
 (never called) and are not provided; ``lstm`` (modules.py:207-243) is reachable only with
-``use_lstm`` true, which no shipped configuration sets -> ``CBHG(use_lstm=True)`` raises.
+``use_lstm`` true, which no shipped configuration sets: provided for inference (an any-size
+recurrence kernel, not a tuned one); training with use_lstm raises.
 """
 import contextlib
 import ctypes as C
@@ -116,10 +117,13 @@ class VariableStore:
         torch = _torch()
         for n, v in self.vars.items():
             if n in d:
-                a = np.ascontiguousarray(d[n], dtype=np.float32)
+                a = np.asarray(d[n], dtype=np.float32)
+                if v.dim() == 0 and a.size == 1:             # scalars (np.ascontiguousarray would make them 1-d)
+                    a = a.reshape(())
+                a = np.ascontiguousarray(a) if a.ndim else a
                 if tuple(a.shape) != tuple(v.shape):
                     raise ValueError(' - ERROR, checkpoint tensor {} has shape {}, model wants {}'.format(n, a.shape, tuple(v.shape)))
-                v.copy_(torch.from_numpy(a))
+                v.copy_(torch.from_numpy(np.array(a)) if a.ndim == 0 else torch.from_numpy(a))
         self.invalidate()
 
     def to_numpy(self):
@@ -500,8 +504,40 @@ def _gru_recurrence(xproj, N_, T_, H, wh_fw, wh_bw):
     return out
 
 
+def _prep_lstm(store, scope, cin, H, bidirection):
+    """tf.contrib.rnn.LSTMCell variables: <scope>/bidirectional_rnn/{fw,bw}/lstm_cell/{kernel [cin+H, 4H], bias [4H]}
+    (or <scope>/rnn/lstm_cell/... for the unidirectional form)."""
+    dirs = ('bidirectional_rnn/fw', 'bidirectional_rnn/bw') if bidirection else ('rnn', 'rnn')
+    w = []
+    for d in dirs:
+        s = '{}/{}/lstm_cell'.format(scope, d)
+        w.append((store.get(s + '/kernel', (cin + H, 4 * H), 'glorot'), store.get(s + '/bias', (4 * H,), 0.0)))
+
+    def build():
+        torch = _torch()
+        btx = torch.cat([k[:cin].t() for k, _ in w], 0).contiguous().to(store.dtype)        # [8H, cin]
+        bx = torch.cat([b for _, b in w], 0).contiguous()
+        wh = [k[cin:].contiguous().to(store.dtype) for k, _ in w]
+        return btx, bx, wh[0], wh[1]
+    return store.cached(('lstm', scope, bidirection), build)
+
+
 def lstm(inputs, num_units=None, bidirection=False, scope="lstm", use_Cudnn=False, reuse=None):
-    raise NotImplementedError(' - ERROR, lstm: no shipped configuration sets use_lstm (modules.py:207-243)')
+    """modules.py:207-243: LSTMCell (no peepholes, forget_bias 1.0) under (bidirectional_)dynamic_rnn; the input
+    halves of both directions are one GEMM, the recurrence one launch (vc_lstm_bidir).  Inference only."""
+    torch = _torch()
+    store = _store()
+    x = _as3(inputs)
+    N_, T_, Cin = x.shape
+    H = Cin if num_units is None else num_units
+    btx, bx, wh_fw, wh_bw = _prep_lstm(store, _scope(scope), Cin, H, bidirection)
+    xproj = torch.empty((N_ * T_, 8 * H), dtype=torch.float32, device=x.device)
+    gemm_launch(x, N_ * T_, T_, Cin, Cin, 8 * H, [(btx, Cin, 1, 0, 0)], xproj, 8 * H, store.vc_dtype,
+                epi_shift=bx, out_f32=True)
+    out = torch.empty((N_, T_, 2 * H), dtype=store.dtype, device=x.device)
+    _vc.check(_vc.lib().vc_lstm_bidir(xproj.data_ptr(), wh_fw.data_ptr(), wh_bw.data_ptr(), store.vc_dtype, N_, T_, H,
+                                      out.data_ptr(), store.vc_dtype, _vc.current_stream()))
+    return out if bidirection else out[:, :, :H].contiguous()
 
 
 def _dropout(x, rate, is_training):
@@ -621,8 +657,8 @@ def highway_chain(inputs, num_units, n_layers, scope_fmt='highwaynet_{}', gru_sc
 def CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dropout_rate=0.5, is_training=True,
          scope="CBHG", use_Cudnn=False, use_lstm=False, reuse=None):
     """modules.py:323-356.  [N, T, E/2] -> [N, T, E]."""
-    if use_lstm:
-        raise NotImplementedError(' - ERROR, CBHG: use_lstm is not used by any shipped configuration')
+    if use_lstm and is_training:
+        raise NotImplementedError(' - ERROR, CBHG: use_lstm is built for inference only (no shipped configuration sets it)')
     with variable_scope(scope):
         # max pooling (modules.py:331) rides on the bank launch's stores where that kernel can do it,
         # else on conv1d_1's operand load (2: operand is post-ReLU (>= 0), integer-ordered max)
@@ -631,7 +667,10 @@ def CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dro
                      activation_fn='relu', pool_input=0 if pooled else 2)                  # (N, T, E/2)
         enc = conv1d(enc, filters=embed_size // 2, size=3, scope="conv1d_2", bn_scope="conv1d_2",
                      residual=inputs)                                                      # + residual
-        # highway blocks + bidirectional GRU (modules.py:342-346)
+        # highway blocks + bidirectional GRU (modules.py:342-354; LSTM when use_lstm)
+        if use_lstm:
+            enc = highway_chain(enc, embed_size // 2, num_highwaynet_blocks)
+            return lstm(enc, num_units=embed_size // 2, bidirection=True)                       # (N, T, E)
         output = highway_chain(enc, embed_size // 2, num_highwaynet_blocks, gru_scope='gru')    # (N, T, E)
     return output
 
@@ -741,7 +780,8 @@ def softmax_argmax_dual(logits, pad_to):
     return prob, cls, prob16
 
 
-def create_stage_variables(store, scope, in_features, embed_size, num_conv_banks, num_highwaynet_blocks, n_output):
+def create_stage_variables(store, scope, in_features, embed_size, num_conv_banks, num_highwaynet_blocks, n_output,
+                           use_lstm=False):
     """Create (if absent) every variable of one prenet -> CBHG -> dense(n_output) stage under
     ``scope`` with TensorFlow's default initialisers, in graph order, WITHOUT launching kernels
     (so checkpoints can be restored before the first forward).  Names as in the reference's
@@ -767,6 +807,11 @@ def create_stage_variables(store, scope, in_features, embed_size, num_conv_banks
         store.get(hs + '/dense2/kernel', (H, H), 'glorot')
         store.get(hs + '/dense2/bias', (H,), -1.0)
     for d in ('fw', 'bw'):
+        if use_lstm:
+            ls = scope + '/CBHG/lstm/bidirectional_rnn/{}/lstm_cell'.format(d)
+            store.get(ls + '/kernel', (2 * H, 4 * H), 'glorot')
+            store.get(ls + '/bias', (4 * H,), 0.0)
+            continue
         gs = scope + '/CBHG/gru/bidirectional_rnn/{}/gru_cell'.format(d)
         store.get(gs + '/gates/kernel', (2 * H, 2 * H), 'glorot')
         store.get(gs + '/gates/bias', (2 * H,), 1.0)

@@ -259,6 +259,53 @@ def test_gru_unidirectional(dtype):
     _close(y, mo.gru_direction(cast(x), w, 'g/gru/rnn'), 5e-5 if dtype == 'float32' else 3e-2, 'gru unidirectional')
 
 
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('H,T,bidir', [(40, 60, True), (128, 24, True), (72, 33, False)])
+def test_lstm(dtype, H, T, bidir):
+    """modules.lstm (modules.py:207-243: LSTMCell defaults, forget_bias 1.0, gate order i, j, f, o) vs the oracle's
+    restatement (parity unpinned at the TensorFlow boundary: the reference ships no LSTM graph)."""
+    import modules
+    rng = np.random.RandomState(H + T)
+    N = 3
+    st = _store(dtype)
+    x = torch.from_numpy((0.7 * rng.standard_normal((N, T, H))).astype(np.float32))
+    with modules.variable_store(st), modules.variable_scope('l'):
+        modules.lstm(modules.convert(x.cuda(), st.dtype), num_units=H, bidirection=bidir)
+        for n, v in list(st.vars.items()):
+            if n.endswith('bias'):
+                st.assign(n, rng.uniform(-0.3, 0.3, tuple(v.shape)).astype(np.float32))
+        y = modules.lstm(modules.convert(x.cuda(), st.dtype), num_units=H, bidirection=bidir)
+    assert y.shape == (N, T, 2 * H if bidir else H)
+    cast = (lambda t: t.double()) if dtype == 'float32' else (lambda t: t.float().bfloat16().double())
+    w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
+    ref = mo.lstm_bidirectional(cast(x), w, 'l/lstm') if bidir else mo.lstm_direction(cast(x), w, 'l/lstm/rnn')
+    _close(y, ref, 5e-5 if dtype == 'float32' else 3e-2, 'lstm H=%d' % H)
+
+
+def test_cbhg_with_lstm_small_decoder():
+    """use_lstm = true through the model objects (decoder_specs -> CBHG -> lstm), inference, float32, vs the oracle."""
+    from decoder import decoder_specs
+    cfg = {'model_name': 'decoder', 'input_shape': [40, 61], 'dropout_rate': 0.1, 'is_training': False,
+           'use_Cudnn': False, 'use_lstm': True, 'use_target_mel_step2': False, 'mel_loss_weight': 400,
+           'stft_loss_weight': 400, 'loss_type': 'sum',
+           'steps_v': [{'embed_size': 64, 'num_conv_banks': 5, 'num_highwaynet_blocks': 2, 'n_output': 80},
+                       {'embed_size': 96, 'num_conv_banks': 4, 'num_highwaynet_blocks': 1, 'n_output': 201}]}
+    dec = decoder_specs(cfg, None, None)
+    assert 'decoder/step1/CBHG/lstm/bidirectional_rnn/fw/lstm_cell/kernel' in dec.store.vars
+    assert not any('/gru/' in n for n in dec.store.vars)
+    rng = np.random.RandomState(8)
+    for n, v in list(dec.store.vars.items()):
+        if n.endswith('bias') or n.endswith('beta') or n.endswith('moving_mean'):
+            dec.store.assign(n, rng.uniform(-0.2, 0.2, tuple(v.shape)).astype(np.float32))
+        elif n.endswith('gamma') or n.endswith('moving_variance'):
+            dec.store.assign(n, rng.uniform(0.5, 1.5, tuple(v.shape)).astype(np.float32))
+    ppg = torch.softmax(torch.from_numpy(rng.standard_normal((2, 40, 61)) * 2), -1).float().numpy()
+    r = dec.predict(ppg)
+    w = {k: v.cpu().double() for k, v in dec.store.vars.items()}
+    ym, ys = mo.decoder_forward(torch.from_numpy(ppg).double(), w, cfg)
+    assert np.abs(r.y_mel - ym.numpy()).max() < 1e-4 and np.abs(r.y_stft - ys.numpy()).max() < 1e-4
+
+
 @pytest.mark.parametrize('N,T,cin,K', [(3, 100, 128, 32), (2, 400, 64, 4), (4, 255, 64, 2), (7, 64, 128, 6)])
 def test_conv1d_banks_pooled_output(N, T, cin, K):
     """epi_pool: the bank launch stores max_pooling1d(2, 1, 'same') of its result (modules.py:331);

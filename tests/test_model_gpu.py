@@ -244,3 +244,16 @@ def test_forced_mfma_recurrence_on_small_chunks_under_stream_overlap(golden_dir)
         torch.cuda.synchronize()
     finally:
         _vc.set_option('gru_mfma', -1)
+
+
+def test_forward_rejects_non_float32_features(golden_dir):
+    """forward() takes float32 device features (predict() / run() convert host arrays); a float64 tensor would be read
+    as the wrong type by the kernels, so it is refused loudly."""
+    from encoder import encoder_spec_phn
+    enc = encoder_spec_phn(_enc_cfg(golden_dir, 'bfloat16'), None)
+    enc.restore()
+    g = np.load(os.path.join(golden_dir, 'encoder_fwd.npz'))
+    with pytest.raises(ValueError, match='float32'):
+        enc.forward(torch.from_numpy(g['x'].astype(np.float64)).cuda())
+    with pytest.raises(ValueError, match='float32'):
+        enc.forward(torch.from_numpy(g['x']))                      # host tensor
