@@ -38,10 +38,14 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 // LDS carve (floats): xs | A_re | A_im | scalars.  (Reading the samples straight from global memory in the 25-point
 // stage -- no sample buffer, one barrier fewer -- measured 6-12 % SLOWER: 50 loads per thread against 14.)
-constexpr int O_XS = 0, O_ARE = SPAN, O_AIM = O_ARE + PT_FLOATS, O_SC = O_AIM + PT_FLOATS, LDS_FLOATS = O_SC + 48;
+// The k1 = 0 rows are real (a real-input DFT's DC term): their imaginary halves are not stored, which is what lets a
+// FIFTH block fit a CU's 160 KB (32,192 B each).
+constexpr int IM_FLOATS = G * 12 * 16;              // 192 imaginary rows
+constexpr int O_XS = 0, O_ARE = SPAN, O_AIM = O_ARE + PT_FLOATS, O_SC = O_AIM + IM_FLOATS, LDS_FLOATS = O_SC + 48;
 static_assert(PT_FLOATS >= G * NB + 16, "power tile aliases a row buffer");
 static_assert(G * NM <= SPAN, "mel dB tile aliases the sample buffer");
-static_assert(G * NC + G * NM <= PT_FLOATS, "cepstra + sum/difference tiles alias the second row buffer");
+static_assert(G * NC + G * NM <= IM_FLOATS, "cepstra + sum/difference tiles alias the second row buffer");
+static_assert(5 * LDS_FLOATS * 4 <= 160 * 1024, "five blocks per CU");
 
 __device__ __forceinline__ int utt_len(const Fe400Args& a, int b) {
     const int L = a.lens ? a.lens[b] : a.max_samples;
@@ -60,7 +64,7 @@ __device__ __forceinline__ float mel_db_clipped(float v, float offm, float mfloo
 __device__ __forceinline__ int row_at(int r, int n2) { return r * 16 + ((((n2 >> 2) ^ (r >> 2)) & 3) << 2) + (n2 & 3); }
 
 template <bool STATS>
-__global__ void __launch_bounds__(NT, 4)
+__global__ void __launch_bounds__(NT, 5)
 fe400_kernel(Fe400Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const xs = smem + O_XS;
@@ -156,14 +160,13 @@ fe400_kernel(Fe400Args a) {
 #pragma unroll
         for (int k1 = 1; k1 < 13; ++k1) { twr[k1] = a.win_tw[400 + k1 * 16 + n2]; twi[k1] = a.win_tw[608 + k1 * 16 + n2]; }
         vcfe::rdft25_13(v, ar, ai);
-        const int r0 = g * 13;
-        Are[row_at(r0, n2)] = ar[0];
-        Aim[row_at(r0, n2)] = ai[0];
+        const int r0 = g * 13, i0 = g * 12 - 1;
+        Are[row_at(r0, n2)] = ar[0];                    // ai[0] == 0: not stored
 #pragma unroll
         for (int k1 = 1; k1 < 13; ++k1) {
             vcfe::cmul(ar[k1], ai[k1], twr[k1], twi[k1]);
             Are[row_at(r0 + k1, n2)] = ar[k1];
-            Aim[row_at(r0 + k1, n2)] = ai[k1];
+            Aim[row_at(i0 + k1, n2)] = ai[k1];
         }
     }
     __syncthreads();
@@ -176,12 +179,15 @@ fe400_kernel(Fe400Args a) {
         float zr[16], zi[16], yr[16], yi[16];
         const int r = row_ok ? tid : 0;
         const int key = (r >> 2) & 3;
+        const bool has_im = row_ok && k13 > 0;
+        const int ri = has_im ? g3 * 12 + k13 - 1 : 0;
+        const int keyi = (ri >> 2) & 3;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f4 vr = *reinterpret_cast<const f4*>(Are + r * 16 + ((q ^ key) << 2));
-            const f4 vi = *reinterpret_cast<const f4*>(Aim + r * 16 + ((q ^ key) << 2));
+            const f4 vi = *reinterpret_cast<const f4*>(Aim + ri * 16 + ((q ^ keyi) << 2));
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { zr[4 * q + e] = vr[e]; zi[4 * q + e] = vi[e]; }
+            for (int e = 0; e < 4; ++e) { zr[4 * q + e] = vr[e]; zi[4 * q + e] = has_im ? vi[e] : 0.0f; }
         }
         vcfe::cdft16(zr, zi, yr, yi);
 #pragma unroll

@@ -1,36 +1,36 @@
 #!/bin/bash
-# Collects the round's evidence on the GPU box into gpurun_out/r01 (copied to profiles/r01 afterwards).
+# Collects the round's evidence on the GPU box into gpurun_out/r02 (copied to profiles/r02 afterwards).
 # usage: bash tools/collect_profiles.sh     (from the repo root, on the MI355X box)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-O=$R/gpurun_out/r01
+O=$R/gpurun_out/r02
 rm -rf $O; mkdir -p $O
 cd $R
 timeout -k 10 300 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smoke exit $?" >> $O/smoke.log
-timeout -k 10 300 python bench.py > $O/bench_full.log 2>&1
+timeout -k 10 400 python bench.py > $O/bench_full.log 2>&1
 timeout -k 10 200 python bench.py --workload frontend --steps 50 --warmup 5 > $O/bench_frontend.log 2>&1
 timeout -k 10 300 python bench.py --workload train --steps 3 --warmup 1 > $O/bench_train.log 2>&1
 timeout -k 10 200 python bench.py --workload vocoder --steps 5 --warmup 1 > $O/bench_vocoder.log 2>&1
-timeout -k 10 200 python bench.py --dtype float32 --steps 5 --warmup 1 --no-cpu-baseline > $O/bench_full_f32.log 2>&1
+for f in bench_full bench_frontend bench_train bench_vocoder; do tail -1 $O/$f.log > $O/$f.json; done
 cd /tmp && export TMPDIR=/tmp
 for W in full frontend train vocoder; do
-  EXTRA="--steps 5 --warmup 1 --no-cpu-baseline"; [ $W = train ] && EXTRA="--steps 2 --warmup 1"; [ $W = vocoder ] && EXTRA="--steps 2 --warmup 1 --no-cpu-baseline"
+  EXTRA="--steps 5 --warmup 1 --no-cpu-baseline --no-f32"; [ $W = train ] && EXTRA="--steps 2 --warmup 1 --no-cpu-baseline"; [ $W = vocoder ] && EXTRA="--steps 2 --warmup 1 --no-cpu-baseline"
+  [ $W = frontend ] && EXTRA="--steps 50 --warmup 5 --no-cpu-baseline"
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$W -- python3 $R/bench.py --workload $W $EXTRA > $O/trace_$W.log 2>&1
   cp $O/trace_$W/*/*kernel_stats.csv $O/${W}_kernel_stats.csv 2>/dev/null
 done
-# the roofline kernel alone (bench.py's rocprof average mixes the step-1 and step-2 filter banks under one name)
+# the roofline kernel alone, >= 50 launches (bench.py's rocprof average mixes the step-1 and step-2 filter banks under one name)
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bank -- python3 $R/tools/prof_kernels.py bank > $O/trace_bank.log 2>&1
 cp $O/trace_bank/*/*kernel_stats.csv $O/bank_step2_kernel_stats.csv 2>/dev/null
-for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES" "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES" "SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE"; do
   N=$(echo $C | tr " " "_" | cut -c1-20)
   timeout -k 10 200 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$N -- python3 $R/tools/prof_kernels.py all > $O/pmc_$N.log 2>&1
 done
 python3 - <<PY
 import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-names = {'bank256_kernel': 'bank256_kernel_bf16_step2', 'conv_kernelIDF16bLi0': 'conv_kernel_bf16_pro0', 'conv_kernelIDF16bLi1': 'conv_kernel_bf16_proj1_step2',
-         'gru_resident_kernelILi256': 'gru_resident_256', 'fe_power400': 'fe_power400_kernel',
-         'fe_finalize': 'fe_finalize_kernel', 'fe_abssum': 'fe_abssum_kernel',
+names = {'bank256_kernel': 'bank256_kernel_bf16_step2', 'conv256_kernel': 'conv256_kernel_bf16', 'gru_mfma_kernelILi256': 'gru_mfma_256',
+         'gru_mfma_kernel<256>': 'gru_mfma_256', 'fe400_kernel<true>': 'fe400_stats_pass', 'fe400_kernel<false>': 'fe400_feature_pass',
          'gl_iter400_kernel<false>': 'gl_iter400_kernel', 'cbhg_small_kernel': 'cbhg_small_kernel'}
 for f in glob.glob('$O/pmc_*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
@@ -47,4 +47,5 @@ for k, v in agg.items():
 json.dump(out, open('$O/pmc_summary.json', 'w'), indent=1, sort_keys=True)
 print(json.dumps({k: v.get('traffic_bytes_per_launch') for k, v in out.items()}))
 PY
-tail -2 $O/smoke.log; for f in bench_full bench_frontend bench_train bench_vocoder bench_full_f32; do tail -1 $O/$f.log | cut -c1-330; done
+rm -rf $O/trace_* $O/pmc_*/                  # keep the summaries (csv / json / logs), not the raw traces
+tail -2 $O/smoke.log; for f in bench_full bench_frontend bench_train bench_vocoder; do cut -c1-400 $O/$f.json; done
