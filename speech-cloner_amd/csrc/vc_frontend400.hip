@@ -36,6 +36,20 @@ constexpr float DB10 = 3.0102999566398120f;         // 10 log10(x) = DB10 * log2
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// In-kernel phase stamps (s_memtime), -DVC_ABLATE builds only (tools/fe_phase_stamps.py reads them back): wave 0 of
+// every block writes the shader clock at each phase boundary into an unused part of the workspace.  The shipped
+// library contains none of this.
+#ifdef VC_ABLATE
+#define FE_STAMP(i)                                                                                         \
+    do {                                                                                                    \
+        if (threadIdx.x == 0)                                                                               \
+            reinterpret_cast<unsigned long long*>(a.mel0 + 65536)[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = \
+                __builtin_amdgcn_s_memtime();                                                               \
+    } while (0)
+#else
+#define FE_STAMP(i) do { } while (0)
+#endif
+
 // LDS carve (floats): xs | A_re | A_im | scalars.  (Reading the samples straight from global memory in the 25-point
 // stage -- no sample buffer, one barrier fewer -- measured 6-12 % SLOWER: 50 loads per thread against 14.)
 // The k1 = 0 rows are real (a real-input DFT's DC term): their imaginary halves are not stored, which is what lets a
@@ -100,6 +114,7 @@ fe400_kernel(Fe400Args a) {
         return;
     }
 
+    FE_STAMP(0);
     // ---------------- tables this thread needs in registers (L2 hits; issued before anything waits)
     const int g = tid >> 4, n2 = tid & 15;
     float wreg[25];
@@ -147,7 +162,9 @@ fe400_kernel(Fe400Args a) {
             }
         }
     }
+    FE_STAMP(1);
     __syncthreads();
+    FE_STAMP(2);
 
     // ---------------- steps 1 + 2: thread (g, n2): real 25-point DFT over n1, twiddle W400^(n2 k1)
     {
@@ -169,7 +186,9 @@ fe400_kernel(Fe400Args a) {
             Aim[row_at(i0 + k1, n2)] = ai[k1];
         }
     }
+    FE_STAMP(3);
     __syncthreads();
+    FE_STAMP(4);
 
     // ---------------- step 3: thread (g3, k13) = row tid: complex 16-point DFT over n2 -> |Y|^2
     const int g3 = tid / 13, k13 = tid - g3 * 13;
@@ -193,7 +212,9 @@ fe400_kernel(Fe400Args a) {
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) pw[k2] = yr[k2] * yr[k2] + yi[k2] * yi[k2];
     }
+    FE_STAMP(5);
     __syncthreads();                                    // every row is in registers: the row buffers are free
+    FE_STAMP(6);
     // power tile: bin k1 + 25 k2 directly for k2 <= 7 (and 200 = 0 + 25 * 8); the bins with residue 13..24 are the
     // mirror images 400 - k of the outputs with k2 >= 8 (hermitian symmetry, fe_dft400.h bin_of)
     float pmax = NEG_INF, pmin = POS_INF;
@@ -242,7 +263,9 @@ fe400_kernel(Fe400Args a) {
 
     if constexpr (STATS) {
         float mmax = NEG_INF, mmin = POS_INF;
+        FE_STAMP(7);
         __syncthreads();                                // power tile complete
+        FE_STAMP(8);
         if (mg < 3) {
             for (int gg = mg; gg < G; gg += 3) {
                 const float* p = Pt + gg * NB + ms;
@@ -270,6 +293,7 @@ fe400_kernel(Fe400Args a) {
             float* s = a.stats + ((size_t)b * a.nt1 + blockIdx.x) * 8;
             s[0] = pmax; s[1] = pmin; s[2] = mmax; s[3] = mmin; s[4] = asum;
         }
+        FE_STAMP(9);
         return;
     } else {
         // ---------------- per-utterance constants from pass 1's tile records (wave 0)
@@ -339,7 +363,9 @@ fe400_kernel(Fe400Args a) {
             }
             if (tid == 0) sc[7] = c00;
         }
+        FE_STAMP(7);
         __syncthreads();                                // power tile + constants
+        FE_STAMP(8);
         const float pA = sc[0], pB = sc[1], pF = sc[2], offm = sc[3], mfloor = sc[4], mS = sc[5], mM = sc[6], c00 = sc[7];
         const int nvalid = min(GO, F - fo);             // output frames that exist
         const int nrows = min(GO, a.max_frames - fo);   // output rows of the buffers (the rest of them: zeros)
@@ -357,6 +383,7 @@ fe400_kernel(Fe400Args a) {
                 o[i] = i < tv ? w : 0.0f;
             }
         }
+        FE_STAMP(9);
         // ---------------- mel power -> dB of the "amplitude" (quirk) -> top_db clip: all 16 frames (DCT halo)
         if (mg < 3) {
             for (int gg = mg; gg < G; gg += 3) {
@@ -369,6 +396,7 @@ fe400_kernel(Fe400Args a) {
             }
         }
         __syncthreads();
+        FE_STAMP(10);
         // ---------------- M_dB out (float4 rows) and the sum / difference halves for the DCT
         {
             const bool clip = a.clip != 0;
@@ -391,6 +419,7 @@ fe400_kernel(Fe400Args a) {
             }
         }
         __syncthreads();
+        FE_STAMP(11);
         // ---------------- DCT-II: coefficient ci (even: sums, odd: differences), frames cf, cf + 6, cf + 12
         if (tid < 240) {
             const float norm = a.mfcc_norm;
@@ -410,6 +439,7 @@ fe400_kernel(Fe400Args a) {
             }
         }
         __syncthreads();
+        FE_STAMP(12);
         // ---------------- [MFCC | delta] out (audio_lib.py:226-228, 238): delta = 2 (M[t+1] - M[t-1]), 0 at both ends
         {
             const bool clip = a.clip != 0;
@@ -436,6 +466,7 @@ fe400_kernel(Fe400Args a) {
                 o[i] = v;
             }
         }
+        FE_STAMP(13);
     }
 }
 
