@@ -191,24 +191,20 @@ bank256_kernel(Bank256Args a) {
     };
 
     // ---------------- prologue
-    auto load_coef = [&]() {   // BatchNorm scale / shift of the pair's 256 channels -> LDS (read again only in the epilogue)
+    {   // BatchNorm scale / shift of the pair's 256 channels -> LDS (read again only in the epilogue)
         float* coef = reinterpret_cast<float*>(smem + COEF_OFF);
         const int ch = tid & 255, oc = (ch < 128 ? pr.c_off0 : pr.c_off1) + (ch & 127);
         const float* src = tid < 256 ? a.epi_scale : a.epi_shift;
         coef[tid] = src ? src[oc] : (tid < 256 ? 1.0f : 0.0f);
-    };
-    if (!ABL(32)) load_coef();
+    }
     stageA(0, 0);
     stageB(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (ntiles > 1) stageB(1, 1);
     if (nslab > 1) stageA(1, 1);
-    if (ABL(32)) load_coef();               // A/B: the coefficient load's latency behind the first tiles' requests
     int j = tap_setup(0);
     load_frags(0, 0, 0);
-    const bool static_prio = ABL(16);       // A/B: one s_setprio 1 for the younger half (waves 4-7), no per-cluster flips
-    if (static_prio && wid >= 4) __builtin_amdgcn_s_setprio(1);
 
 #ifndef B256_RP
 #define B256_RP 2        // fragment-read placement: 0 = ahead of the step's MFMAs, 1 = between them, 2 = pinned after 2 MFMAs
@@ -256,7 +252,7 @@ bank256_kernel(Bank256Args a) {
                 fb[nxt][1] = *reinterpret_cast<const bf16x8*>(bp + 4096);
             }
 #endif
-            if (!static_prio) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
             acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][0], av[0], acc[0][0], 0, 0, 0);
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[cur][1], av[0], acc[0][1], 0, 0, 0);
 #if B256_RP != 0
@@ -316,7 +312,7 @@ bank256_kernel(Bank256Args a) {
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
 #endif
-            if (!static_prio) __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_setprio(0);
         }
         j = jn;
     };

@@ -47,16 +47,25 @@ enum Option {
 int opt(Option o);        // current value, -1 if unset
 
 #if defined(__HIPCC__)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+// Wave-wide reductions on DPP (data-parallel primitives: the cross-lane operand of a VALU instruction), result in every
+// lane.  __shfl_xor lowers to ds_bpermute_b32 on gfx950 -- an LDS-path round trip of ~100 cycles per step, 6 dependent
+// steps per reduction; the DPP form is 6 plain vector instructions (quad swaps, half-row / row mirrors, then the
+// row_bcast:15 / row_bcast:31 carries of the GFX9 family) and one v_readlane.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float identity, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(identity), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+#define VC_WAVE_REDUCE(OP, ID)                                                                  \
+    v = OP(v, dpp_move<0xB1, 0xF>(ID, v));     /* quad_perm [1,0,3,2] */                        \
+    v = OP(v, dpp_move<0x4E, 0xF>(ID, v));     /* quad_perm [2,3,0,1] */                        \
+    v = OP(v, dpp_move<0x141, 0xF>(ID, v));    /* row_half_mirror */                            \
+    v = OP(v, dpp_move<0x140, 0xF>(ID, v));    /* row_mirror: every lane of a row of 16 */      \
+    v = OP(v, dpp_move<0x142, 0xA>(ID, v));    /* row_bcast:15 into rows 1 and 3 */             \
+    v = OP(v, dpp_move<0x143, 0xC>(ID, v));    /* row_bcast:31 into rows 2 and 3 */             \
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+__device__ __forceinline__ float vc_addf(float a, float b) { return a + b; }
+__device__ __forceinline__ float wave_sum(float v) { VC_WAVE_REDUCE(vc_addf, 0.0f) }
+__device__ __forceinline__ float wave_max(float v) { VC_WAVE_REDUCE(fmaxf, -3.402823466e38f) }
 // highwaynet gate (modules.py:315-319): relu(h) * t + x * (1 - t), t = sigmoid(tpre), written as
 // x + t * (relu(h) - x) with v_exp_f32 / v_rcp_f32 (1 ulp each) -- the gate arithmetic, not the
 // matrix work, bounds the fused highway chain, and an IEEE division costs ~10 instructions.
@@ -67,11 +76,8 @@ __device__ __forceinline__ float highway_gate(float hpre, float tpre, float x) {
     const float tv = __builtin_amdgcn_rcpf(1.0f + e);
     return fmaf(tv, hv - x, x);
 }
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ float wave_min(float v) { VC_WAVE_REDUCE(fminf, 3.402823466e38f) }
+#undef VC_WAVE_REDUCE
 #endif
 
 }  // namespace vc

@@ -73,12 +73,31 @@ __device__ __forceinline__ float mel_db_clipped(float v, float offm, float mfloo
     return fmaxf(fmaf(2.0f * DB10, __log2f(fmaxf(v, 1e-18f)), offm), mfloor);
 }
 
+// power_to_db (audio_lib.py:157: 10 log10(max(1e-10, P)), then the top_db floor) with the amplitude-normalisation offset;
+// the amin clamp sits 200 dB under the 1e-30 used here once the offset is added back, i.e. below every floor >= -100.
+__device__ __forceinline__ float pow_db_clipped(float v, float offp, float pfloor) {
+    return fmaxf(fmaf(DB10, __log2f(fmaxf(v, 1e-30f)), offp), pfloor);
+}
+
+// One filter of the sparse mel matrix on one frame: 14 reads issued together (reads past the filter's own count meet
+// zero weights; past the tile's last row they meet the zero pad), then one FMA chain.  A per-term `if (j < count)`
+// here serialised every LDS round trip behind a branch: 10,280 of a block's 20,810 cycles (s_memtime stamps).
+__device__ __forceinline__ float mel_dot(const float* p, const float (&w)[14]) {
+    float v[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) v[j] = p[j];
+    float acc = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 14; ++j) acc = fmaf(w[j], v[j], acc);
+    return acc;
+}
+
 // physical float index of element n2 of row r in a row buffer: 16 floats per row, the 16-byte chunk XORed with
 // (r >> 2) & 3 so that the 16 lanes of a ds_read_b128 group (16 consecutive rows) hit 16 different 4-bank groups
 __device__ __forceinline__ int row_at(int r, int n2) { return r * 16 + ((((n2 >> 2) ^ (r >> 2)) & 3) << 2) + (n2 & 3); }
 
 template <bool STATS>
-__global__ void __launch_bounds__(NT, 5)
+__global__ void __launch_bounds__(NT, STATS ? 5 : 4)
 fe400_kernel(Fe400Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* const xs = smem + O_XS;
@@ -120,7 +139,34 @@ fe400_kernel(Fe400Args a) {
     float wreg[25];
 #pragma unroll
     for (int n1 = 0; n1 < 25; ++n1) wreg[n1] = a.win_tw[16 * n1 + n2];
+    // sparse mel row of this thread (m, frame group): its descriptor now, its <= 14 weights behind the 25-point stage's
+    // operand reads -- two dependent L2 round trips that used to sit, exposed, in front of the mel loop
+    const int mm = tid % NM, mg = tid / NM;             // mg = 3: idle lanes of the last wave
+    int ms = 0, mo = 0, mcnt = 0;
+    if (mg < 3) {
+        ms = a.mel_start[mm];
+        mo = a.mel_off[mm];
+        mcnt = a.mel_off[mm + 1] - mo;
+    }
 
+    // ---------------- pass 2, wave 0: the utterance's tile records and frame 0's mel row are requested FIRST, so that
+    // their round trips run beside the block's sample loads; the constants are computed while the samples are in flight
+    float r_pmx = NEG_INF, r_pmn = POS_INF, r_mmx = NEG_INF, r_mmn = POS_INF, r_as = 0.0f, r_v0 = 1.0f, r_v1 = 1.0f;
+    if constexpr (!STATS) {
+        if (tid < 64) {
+            const int nt = (F + G - 1) / G;
+            for (int t = tid; t < nt; t += 64) {
+                const float* s = a.stats + ((size_t)b * a.nt1 + t) * 8;
+                r_pmx = fmaxf(r_pmx, s[0]); r_pmn = fminf(r_pmn, s[1]);
+                r_mmx = fmaxf(r_mmx, s[2]); r_mmn = fminf(r_mmn, s[3]);
+                r_as += s[4];
+            }
+            if (a.first_mfcc && tid < NH) {
+                r_v0 = a.mel0[(size_t)b * NM + tid];
+                r_v1 = a.mel0[(size_t)b * NM + NM - 1 - tid];
+            }
+        }
+    }
     // ---------------- samples: reflect padding of the pre-emphasised signal (np.pad(y_preem, 200, 'reflect'))
     // The amplitude normalisation (audio_lib.py:125-126: y *= norm / mean|y|) is linear all the way to the power
     // spectrum, so it is applied as a dB offset once mean|y| is known (pass 2).
@@ -148,6 +194,48 @@ fe400_kernel(Fe400Args a) {
                 prv[u] = j > 0 ? x[j - 1] : 0.0f;               // lfilter's zero initial state: y[0] = x[0]
             }
         }
+        if constexpr (!STATS) {
+            if (tid < 64) {
+                const float pmx = vc::wave_max(r_pmx), pmn = vc::wave_min(r_pmn);
+                const float mmx = vc::wave_max(r_mmx), mmn = vc::wave_min(r_mmn);
+                const float as = vc::wave_sum(r_as);
+                // amplitude normalisation as dB offsets: c = norm / mean|x| -> + 20 log10 c on the power dB, + 40 log10 c on
+                // the mel dB; then the amin clamps (10 log10 1e-10 = 20 log10 1e-5 = -100 dB) and top_db = 80
+                float offp = 0.0f;
+                if (a.amp_norm != 1.0f) offp = 2.0f * DB10 * __log2f(a.amp_norm / (as / (float)L));
+                const float offm = 2.0f * offp;
+                // (the same two functions the elements go through below: the utterance's minimum then maps to exactly 0)
+                const float pfloor = fmaxf(pow_db_clipped(pmx, offp, -100.0f) - 80.0f, -100.0f);
+                const float mfloor = fmaxf(mel_db_clipped(mmx, offm, -100.0f) - 80.0f, -100.0f);
+                const float pmin_c = pow_db_clipped(pmn, offp, pfloor), mmin_c = mel_db_clipped(mmn, offm, mfloor);
+                // the min shift and the scale are skipped at factor 1.0 (audio_lib.py:230-235)
+                const bool pn = a.p_norm != 1.0f, mn = a.m_norm != 1.0f;
+                if (tid == 0) {
+                    sc[0] = offp; sc[1] = pfloor;
+                    sc[2] = pn ? a.p_norm : 1.0f;
+                    sc[8] = pn ? pmin_c : 0.0f;
+                    sc[3] = offm; sc[4] = mfloor;
+                    sc[5] = mn ? a.m_norm : 1.0f;
+                    sc[6] = mn ? mmin_c : 0.0f;
+                }
+                // frame 0's first cepstral coefficient (audio_lib.py:221), summed exactly like the tile's own
+                // coefficient 0 below so that frame 0's own value cancels to 0
+                float c00 = 0.0f;
+                if (a.first_mfcc) {
+                    const float d0 = mel_db_clipped(r_v0, offm, mfloor), d1 = mel_db_clipped(r_v1, offm, mfloor);
+                    const float s0 = d0 + d1;
+                    const float dc = a.dct_half[0];                     // row 0 is constant: 1 / sqrt(80)
+                    float acc4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < NH; ++j) {
+                        const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s0), j));
+                        acc4[j & 3] = fmaf(dc, sj, acc4[j & 3]);
+                    }
+                    c00 = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+                }
+                if (tid == 0) sc[7] = c00;
+            }
+        }
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
             const int i = tid + NT * u;
@@ -166,13 +254,20 @@ fe400_kernel(Fe400Args a) {
     __syncthreads();
     FE_STAMP(2);
 
+    float mw_[14];
+#pragma unroll
+    for (int j = 0; j < 14; ++j) mw_[j] = 0.0f;
     // ---------------- steps 1 + 2: thread (g, n2): real 25-point DFT over n1, twiddle W400^(n2 k1)
     {
         const float* xp = xs + g * HOP + n2;
         float v[25], ar[13], ai[13];
 #pragma unroll
         for (int n1 = 0; n1 < 25; ++n1) v[n1] = xp[16 * n1] * wreg[n1];
-        // twiddles: requested here, consumed behind the 25-point transform
+        // twiddles and this thread's mel weights: requested here, consumed behind the 25-point transform
+        if (mg < 3) {
+#pragma unroll
+            for (int j = 0; j < 14; ++j) mw_[j] = a.mel_w[mo + min(j, max(mcnt - 1, 0))];
+        }
         float twr[13], twi[13];
 #pragma unroll
         for (int k1 = 1; k1 < 13; ++k1) { twr[k1] = a.win_tw[400 + k1 * 16 + n2]; twi[k1] = a.win_tw[608 + k1 * 16 + n2]; }
@@ -212,6 +307,19 @@ fe400_kernel(Fe400Args a) {
 #pragma unroll
         for (int k2 = 0; k2 < 16; ++k2) pw[k2] = yr[k2] * yr[k2] + yi[k2] * yi[k2];
     }
+    // DCT basis row of this thread's coefficient (rows of librosa.filters.dct(40, 80), first half): requested here,
+    // used four phases later
+    const int ci = tid / 6, cf = tid - ci * 6;          // coefficient, frame phase (tid < 240)
+    float drow[STATS ? 1 : NH];
+    if constexpr (!STATS) {
+        if (tid < 240) {
+#pragma unroll
+            for (int j = 0; j < NH; j += 4) {
+                const f4 d = *reinterpret_cast<const f4*>(a.dct_half + ci * NH + j);
+                drow[j] = d[0]; drow[j + 1] = d[1]; drow[j + 2] = d[2]; drow[j + 3] = d[3];
+            }
+        }
+    }
     FE_STAMP(5);
     __syncthreads();                                    // every row is in registers: the row buffers are free
     FE_STAMP(6);
@@ -242,25 +350,9 @@ fe400_kernel(Fe400Args a) {
     }
     if (tid < 16) Pt[G * NB + tid] = 0.0f;              // pad behind the last row: the mel loop reads past a row's end
 
-    // ---------------- sparse mel: thread (m, frame group): filter m's <= 14 weights in registers
-    const int mm = tid % NM, mg = tid / NM;             // mg = 3: idle lanes of the last wave
-    float mw_[14];
-    int ms = 0, mcnt = 0;
-    if (mg < 3) {
-        ms = a.mel_start[mm];
-        const int o = a.mel_off[mm];
-        mcnt = a.mel_off[mm + 1] - o;
+    // ---------------- sparse mel: weights beyond the filter's own count are zeroed (the loads above clamp their index)
 #pragma unroll
-        for (int j = 0; j < 14; ++j) mw_[j] = j < mcnt ? a.mel_w[o + j] : 0.0f;
-    } else {
-#pragma unroll
-        for (int j = 0; j < 14; ++j) mw_[j] = 0.0f;
-    }
-    int wcnt = mcnt;                                    // wave-uniform trip count
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) wcnt = max(wcnt, __shfl_xor(wcnt, o, 64));
-    wcnt = __builtin_amdgcn_readfirstlane(wcnt);
-
+    for (int j = 0; j < 14; ++j) mw_[j] = j < mcnt ? mw_[j] : 0.0f;
     if constexpr (STATS) {
         float mmax = NEG_INF, mmin = POS_INF;
         FE_STAMP(7);
@@ -268,11 +360,7 @@ fe400_kernel(Fe400Args a) {
         FE_STAMP(8);
         if (mg < 3) {
             for (int gg = mg; gg < G; gg += 3) {
-                const float* p = Pt + gg * NB + ms;
-                float acc = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 14; ++j)
-                    if (j < wcnt) acc = fmaf(mw_[j], p[j], acc);
+                const float acc = mel_dot(Pt + gg * NB + ms, mw_);
                 if (f0 + gg < F) { mmax = fmaxf(mmax, acc); mmin = fminf(mmin, acc); }
                 if (f0 + gg == 0) a.mel0[(size_t)b * NM + mm] = acc;
             }
@@ -296,77 +384,14 @@ fe400_kernel(Fe400Args a) {
         FE_STAMP(9);
         return;
     } else {
-        // ---------------- per-utterance constants from pass 1's tile records (wave 0)
         float* const Mc = xs;                           // [G][80]  clipped mel dB (the samples are consumed)
         float* const Mf = Aim;                          // [G][40]  scaled cepstra
         float* const SD = Aim + G * NC;                 // [G][80]  j < 40: m[j] + m[79-j], j >= 40: m[j-40] - m[119-j]
-        // DCT basis row of this thread's coefficient (rows of librosa.filters.dct(40, 80), first half)
-        const int ci = tid / 6, cf = tid - ci * 6;      // coefficient, frame phase (tid < 240)
-        float drow[NH];
-        if (tid < 240) {
-#pragma unroll
-            for (int j = 0; j < NH; j += 4) {
-                const f4 d = *reinterpret_cast<const f4*>(a.dct_half + ci * NH + j);
-                drow[j] = d[0]; drow[j + 1] = d[1]; drow[j + 2] = d[2]; drow[j + 3] = d[3];
-            }
-        }
-        if (tid < 64) {
-            const int nt = (F + G - 1) / G;
-            float pmx = NEG_INF, pmn = POS_INF, mmx = NEG_INF, mmn = POS_INF, as = 0.0f;
-            for (int t = tid; t < nt; t += 64) {
-                const float* s = a.stats + ((size_t)b * a.nt1 + t) * 8;
-                pmx = fmaxf(pmx, s[0]); pmn = fminf(pmn, s[1]);
-                mmx = fmaxf(mmx, s[2]); mmn = fminf(mmn, s[3]);
-                as += s[4];
-            }
-            pmx = vc::wave_max(pmx); pmn = vc::wave_min(pmn);
-            mmx = vc::wave_max(mmx); mmn = vc::wave_min(mmn);
-            as = vc::wave_sum(as);
-            // amplitude normalisation as dB offsets: c = norm / mean|x| -> + 20 log10 c on the power dB, + 40 log10 c on
-            // the mel dB; then the amin clamps (10 log10 1e-10 = 20 log10 1e-5 = -100 dB) and top_db = 80
-            float offp = 0.0f;
-            if (a.amp_norm != 1.0f) offp = 2.0f * DB10 * __log2f(a.amp_norm / (as / (float)L));
-            const float offm = 2.0f * offp;
-            const float pmax_db = fmaxf(DB10 * __log2f(fmaxf(pmx, 1e-30f)) + offp, -100.0f);
-            const float pmin_db = fmaxf(DB10 * __log2f(fmaxf(pmn, 1e-30f)) + offp, -100.0f);
-            const float mmax_db = fmaxf(2.0f * DB10 * __log2f(fmaxf(mmx, 1e-18f)) + offm, -100.0f);
-            const float mmin_db = fmaxf(2.0f * DB10 * __log2f(fmaxf(mmn, 1e-18f)) + offm, -100.0f);
-            const float pfloor = fmaxf(pmax_db - 80.0f, -100.0f), mfloor = fmaxf(mmax_db - 80.0f, -100.0f);
-            const float pmin_c = fmaxf(pmin_db, pfloor), mmin_c = fmaxf(mmin_db, mfloor);
-            // out = clip(A log2(P) + B', floor') with the min shift and the scale folded in (skipped at factor 1.0,
-            // audio_lib.py:230-235)
-            const bool pn = a.p_norm != 1.0f, mn = a.m_norm != 1.0f;
-            if (tid == 0) {
-                sc[0] = pn ? a.p_norm * DB10 : DB10;
-                sc[1] = pn ? a.p_norm * (offp - pmin_c) : offp;
-                sc[2] = pn ? a.p_norm * (pfloor - pmin_c) : pfloor;
-                sc[3] = offm; sc[4] = mfloor;
-                sc[5] = mn ? a.m_norm : 1.0f;
-                sc[6] = mn ? mmin_c : 0.0f;
-            }
-            // frame 0's first cepstral coefficient (audio_lib.py:221), summed exactly like the tile's own
-            // coefficient 0 below so that frame 0's own value cancels to 0
-            float c00 = 0.0f;
-            if (a.first_mfcc) {
-                const float v0 = tid < NH ? a.mel0[(size_t)b * NM + tid] : 1.0f;
-                const float v1 = tid < NH ? a.mel0[(size_t)b * NM + NM - 1 - tid] : 1.0f;
-                const float d0 = mel_db_clipped(v0, offm, mfloor), d1 = mel_db_clipped(v1, offm, mfloor);
-                const float s0 = d0 + d1;
-                const float dc = a.dct_half[0];                     // row 0 is constant: 1 / sqrt(80)
-                float acc4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-                for (int j = 0; j < NH; ++j) {
-                    const float sj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s0), j));
-                    acc4[j & 3] = fmaf(dc, sj, acc4[j & 3]);
-                }
-                c00 = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
-            }
-            if (tid == 0) sc[7] = c00;
-        }
         FE_STAMP(7);
         __syncthreads();                                // power tile + constants
         FE_STAMP(8);
-        const float pA = sc[0], pB = sc[1], pF = sc[2], offm = sc[3], mfloor = sc[4], mS = sc[5], mM = sc[6], c00 = sc[7];
+        const float offp = sc[0], pfloor = sc[1], pS = sc[2], pM = sc[8], offm = sc[3], mfloor = sc[4], mS = sc[5], mM = sc[6],
+                    c00 = sc[7];
         const int nvalid = min(GO, F - fo);             // output frames that exist
         const int nrows = min(GO, a.max_frames - fo);   // output rows of the buffers (the rest of them: zeros)
 
@@ -378,7 +403,7 @@ fe400_kernel(Fe400Args a) {
             const bool clip = a.clip != 0;
 #pragma unroll 4
             for (int i = tid; i < tr; i += NT) {
-                float w = fmaxf(fmaf(pA, __log2f(p[i]), pB), pF);
+                float w = pS * (pow_db_clipped(p[i], offp, pfloor) - pM);
                 if (clip) w = fminf(fmaxf(w, -1.0f), 1.0f);
                 o[i] = i < tv ? w : 0.0f;
             }
@@ -387,12 +412,7 @@ fe400_kernel(Fe400Args a) {
         // ---------------- mel power -> dB of the "amplitude" (quirk) -> top_db clip: all 16 frames (DCT halo)
         if (mg < 3) {
             for (int gg = mg; gg < G; gg += 3) {
-                const float* p = Pt + gg * NB + ms;
-                float acc = 0.0f;
-#pragma unroll
-                for (int j = 0; j < 14; ++j)
-                    if (j < wcnt) acc = fmaf(mw_[j], p[j], acc);
-                Mc[gg * NM + mm] = mel_db_clipped(acc, offm, mfloor);
+                Mc[gg * NM + mm] = mel_db_clipped(mel_dot(Pt + gg * NB + ms, mw_), offm, mfloor);
             }
         }
         __syncthreads();
