@@ -28,9 +28,13 @@ constexpr int NT = 256;
 constexpr int G = 16;                 // frames transformed per block
 constexpr int GO = 14;                // output frames per block in pass 2
 constexpr int HOP = 80, NFFT = 400, HALF = 200, NB = 201, NM = 80, NC = 40, NH = 40;
-constexpr int SPAN = HOP * (G - 1) + NFFT;          // 1600 samples under a tile's 16 frames
-constexpr int ROWS = G * 13;                        // (frame, k1) rows of the 16-point stage
-constexpr int PT_FLOATS = ROWS * 16;                // one row buffer (3328 floats) >= 16 * 201 + 16 (power tile + pad)
+constexpr int WSPAN = HOP * 3 + NFFT;               // 640 samples under a wave's 4 frames
+constexpr int RP = 20;                              // row pitch (floats): 16 + 4 pad -> ds_read_b128 of 16 consecutive rows
+                                                    // conflict-free (5 r mod 16 is a permutation), every address an immediate
+constexpr int WROWS = 52;                           // (frame, k1) rows of one wave: 4 frames x 13
+constexpr int RE_W = WROWS * RP;                    // 1040 floats of real parts per wave
+constexpr int IM_W = 48 * RP;                       // 960 floats of imaginary parts per wave (k1 = 0 is real: not stored)
+constexpr int PP = RE_W / 4;                        // 260: pitch of a power-tile row (4 rows per wave region, 59 floats of slack each)
 constexpr float NEG_INF = -3.402823466e38f, POS_INF = 3.402823466e38f;
 constexpr float DB10 = 3.0102999566398120f;         // 10 log10(x) = DB10 * log2(x)
 
@@ -50,16 +54,19 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define FE_STAMP(i) do { } while (0)
 #endif
 
-// LDS carve (floats): xs | A_re | A_im | scalars.  (Reading the samples straight from global memory in the 25-point
-// stage -- no sample buffer, one barrier fewer -- measured 6-12 % SLOWER: 50 loads per thread against 14.)
-// The k1 = 0 rows are real (a real-input DFT's DC term): their imaginary halves are not stored, which is what lets a
-// FIFTH block fit a CU's 160 KB (32,192 B each).
-constexpr int IM_FLOATS = G * 12 * 16;              // 192 imaginary rows
-constexpr int O_XS = 0, O_ARE = SPAN, O_AIM = O_ARE + PT_FLOATS, O_SC = O_AIM + IM_FLOATS, LDS_FLOATS = O_SC + 48;
-static_assert(PT_FLOATS >= G * NB + 16, "power tile aliases a row buffer");
-static_assert(G * NM <= SPAN, "mel dB tile aliases the sample buffer");
-static_assert(G * NC + G * NM <= IM_FLOATS, "cepstra + sum/difference tiles alias the second row buffer");
-static_assert(5 * LDS_FLOATS * 4 <= 160 * 1024, "five blocks per CU");
+// LDS carve (floats): A_re [4 waves][52 rows] | A_im [4 waves][48 rows] | scalars.
+// Everything up to the power tile is WAVE-LOCAL: a wave loads the 640 samples under its own 4 frames (into its own
+// imaginary-row region, which it overwrites only after reading them: LDS operations of one wave execute in order), runs
+// the 25-point stage on them, reads its own 52 rows back for the 16-point stage and writes its 4 power rows over its own
+// real-row region.  No workgroup barrier before "power tile complete", so the four waves of a block -- and the blocks of
+// a CU -- drift apart and one wave's load latency runs under another's arithmetic.  (Measured alternatives, all slower
+// or equal: samples straight from global memory in the 25-point stage, 6-12 % slower (50 loads per thread against 14);
+// a fifth block per CU by XOR-swizzled 16-float rows, no change: resident blocks are not the limit.)
+constexpr int O_ARE = 0, O_AIM = 4 * RE_W, O_SC = O_AIM + 4 * IM_W, LDS_FLOATS = O_SC + 48;
+static_assert(WSPAN <= IM_W, "a wave's samples alias its imaginary rows");
+static_assert(PP >= NB + 14, "a power row plus the mel loop's over-read fit the row pitch");
+static_assert(G * NC + 2 * G * NM <= 4 * IM_W, "cepstra + sum/difference + mel dB tiles alias the imaginary rows");
+static_assert(4 * LDS_FLOATS * 4 <= 160 * 1024, "four blocks per CU");
 
 __device__ __forceinline__ int utt_len(const Fe400Args& a, int b) {
     const int L = a.lens ? a.lens[b] : a.max_samples;
@@ -92,19 +99,17 @@ __device__ __forceinline__ float mel_dot(const float* p, const float (&w)[14]) {
     return acc;
 }
 
-// physical float index of element n2 of row r in a row buffer: 16 floats per row, the 16-byte chunk XORed with
-// (r >> 2) & 3 so that the 16 lanes of a ds_read_b128 group (16 consecutive rows) hit 16 different 4-bank groups
-__device__ __forceinline__ int row_at(int r, int n2) { return r * 16 + ((((n2 >> 2) ^ (r >> 2)) & 3) << 2) + (n2 & 3); }
+// float index of element n2 of row r in a row buffer
+__device__ __forceinline__ int row_at(int r, int n2) { return r * RP + n2; }
 
 template <bool STATS>
-__global__ void __launch_bounds__(NT, STATS ? 5 : 4)
+__global__ void __launch_bounds__(NT, 4)
 fe400_kernel(Fe400Args a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const xs = smem + O_XS;
     float* const Are = smem + O_ARE;
     float* const Aim = smem + O_AIM;
     float* const sc = smem + O_SC;
-    float* const Pt = Are;                              // [G][201] (+ pad) once the rows are in registers
+    float* const Pt = Are;                              // power tile: row g at Pt + g * PP (4 rows per wave region)
 
     const int tid = threadIdx.x, b = blockIdx.y;
     const int L = utt_len(a, b);
@@ -135,7 +140,7 @@ fe400_kernel(Fe400Args a) {
 
     FE_STAMP(0);
     // ---------------- tables this thread needs in registers (L2 hits; issued before anything waits)
-    const int g = tid >> 4, n2 = tid & 15;
+    const int n2 = tid & 15;
     float wreg[25];
 #pragma unroll
     for (int n1 = 0; n1 < 25; ++n1) wreg[n1] = a.win_tw[16 * n1 + n2];
@@ -171,23 +176,28 @@ fe400_kernel(Fe400Args a) {
     // The amplitude normalisation (audio_lib.py:125-126: y *= norm / mean|y|) is linear all the way to the power
     // spectrum, so it is applied as a dB offset once mean|y| is known (pass 2).
     const float* x = a.wav + (size_t)b * a.wav_stride;
-    const int base = f0 * HOP - HALF;
+    const int wv = tid >> 6, lane = tid & 63;           // wave, lane: the wave owns frames f0 + 4 wv .. f0 + 4 wv + 3
+    const int gl = lane >> 4;                           // frame within the wave (== g & 3)
+    float* const are_w = Are + wv * RE_W;               // this wave's 52 real rows (later: its 4 power rows)
+    float* const aim_w = Aim + wv * IM_W;               // this wave's 48 imaginary rows (first: its 640 samples)
+    float* const xs = aim_w;
+    const int fw = f0 + 4 * wv;                         // first frame of the wave
+    const int base = fw * HOP - HALF;
     float asum = 0.0f;
     {
-        const bool interior = base >= 1 && base + SPAN <= L;    // block-uniform: no reflection, no clamping
+        const bool interior = base >= 1 && base + WSPAN <= L;   // wave-uniform: no reflection, no clamping
         const float pe = a.pre_emph;
-        float cur[7], prv[7];
+        float cur[10], prv[10];
         if (interior) {
 #pragma unroll
-            for (int u = 0; u < 7; ++u) {
-                const int i = min(tid + NT * u, SPAN - 1);
-                cur[u] = x[base + i];
-                prv[u] = x[base + i - 1];
+            for (int u = 0; u < 10; ++u) {
+                cur[u] = x[base + lane + 64 * u];
+                prv[u] = x[base + lane + 64 * u - 1];
             }
         } else {
 #pragma unroll
-            for (int u = 0; u < 7; ++u) {
-                const int idx = base + min(tid + NT * u, SPAN - 1);
+            for (int u = 0; u < 10; ++u) {
+                const int idx = base + lane + 64 * u;
                 int j = idx < 0 ? -idx : (idx >= L ? 2 * (L - 1) - idx : idx);
                 j = min(max(j, 0), L - 1);
                 cur[u] = x[j];
@@ -237,29 +247,27 @@ fe400_kernel(Fe400Args a) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < 7; ++u) {
-            const int i = tid + NT * u;
-            if (i < SPAN) {
-                const int idx = base + i;
-                // beyond the reflected tail (idx >= L + 200) no frame of this utterance reads
-                xs[i] = idx < L + HALF ? cur[u] - pe * prv[u] : 0.0f;
-                if constexpr (STATS) {
-                    // sum|x| of the tile's OWN samples [fo*80, (fo+16)*80): every sample counted once per utterance
-                    if (idx >= fo * HOP && idx < min((fo + G) * HOP, L)) asum += fabsf(cur[u]);
-                }
+        for (int u = 0; u < 10; ++u) {
+            const int i = lane + 64 * u;
+            const int idx = base + i;
+            // beyond the reflected tail (idx >= L + 200) no frame of this utterance reads
+            xs[i] = idx < L + HALF ? cur[u] - pe * prv[u] : 0.0f;
+            if constexpr (STATS) {
+                // sum|x| of the wave's OWN hops [fw*80, (fw+4)*80): every sample of the utterance counted once
+                if (idx >= fw * HOP && idx < min((fw + 4) * HOP, L)) asum += fabsf(cur[u]);
             }
         }
     }
     FE_STAMP(1);
-    __syncthreads();
-    FE_STAMP(2);
 
     float mw_[14];
 #pragma unroll
     for (int j = 0; j < 14; ++j) mw_[j] = 0.0f;
-    // ---------------- steps 1 + 2: thread (g, n2): real 25-point DFT over n1, twiddle W400^(n2 k1)
+    // ---------------- steps 1 + 2: lane (gl, n2): real 25-point DFT over n1, twiddle W400^(n2 k1).  Wave-local: the
+    // wave's own LDS writes above are ordered before these reads, and every read of the samples is issued before the
+    // row stores that overwrite them (same wave, in order).
     {
-        const float* xp = xs + g * HOP + n2;
+        const float* xp = xs + gl * HOP + n2;
         float v[25], ar[13], ai[13];
 #pragma unroll
         for (int n1 = 0; n1 < 25; ++n1) v[n1] = xp[16 * n1] * wreg[n1];
@@ -272,34 +280,33 @@ fe400_kernel(Fe400Args a) {
 #pragma unroll
         for (int k1 = 1; k1 < 13; ++k1) { twr[k1] = a.win_tw[400 + k1 * 16 + n2]; twi[k1] = a.win_tw[608 + k1 * 16 + n2]; }
         vcfe::rdft25_13(v, ar, ai);
-        const int r0 = g * 13, i0 = g * 12 - 1;
-        Are[row_at(r0, n2)] = ar[0];                    // ai[0] == 0: not stored
+        // the reads of v[] above must have RETURNED before any row store may land on the sample buffer: the compiler
+        // orders them (ar / ai depend on v), the LDS unit executes a wave's operations in order
+        const int r0 = gl * 13, i0 = gl * 12 - 1;
+        are_w[(r0)*RP + n2] = ar[0];                    // ai[0] == 0: not stored
 #pragma unroll
         for (int k1 = 1; k1 < 13; ++k1) {
             vcfe::cmul(ar[k1], ai[k1], twr[k1], twi[k1]);
-            Are[row_at(r0 + k1, n2)] = ar[k1];
-            Aim[row_at(i0 + k1, n2)] = ai[k1];
+            are_w[(r0 + k1) * RP + n2] = ar[k1];
+            aim_w[(i0 + k1) * RP + n2] = ai[k1];
         }
     }
-    FE_STAMP(3);
-    __syncthreads();
-    FE_STAMP(4);
+    FE_STAMP(2);
 
-    // ---------------- step 3: thread (g3, k13) = row tid: complex 16-point DFT over n2 -> |Y|^2
-    const int g3 = tid / 13, k13 = tid - g3 * 13;
-    const bool row_ok = tid < ROWS;
+    // ---------------- step 3: lane = row (g3l, k13) of the wave's 52: complex 16-point DFT over n2 -> |Y|^2
+    const int g3l = lane / 13, k13 = lane - g3l * 13;
+    const bool row_ok = lane < WROWS;
+    const int g3 = 4 * wv + g3l;                        // frame within the tile
     float pw[16];
     {
         float zr[16], zi[16], yr[16], yi[16];
-        const int r = row_ok ? tid : 0;
-        const int key = (r >> 2) & 3;
+        const int r = row_ok ? lane : 0;
         const bool has_im = row_ok && k13 > 0;
-        const int ri = has_im ? g3 * 12 + k13 - 1 : 0;
-        const int keyi = (ri >> 2) & 3;
+        const int ri = has_im ? g3l * 12 + k13 - 1 : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f4 vr = *reinterpret_cast<const f4*>(Are + r * 16 + ((q ^ key) << 2));
-            const f4 vi = *reinterpret_cast<const f4*>(Aim + ri * 16 + ((q ^ keyi) << 2));
+            const f4 vr = *reinterpret_cast<const f4*>(are_w + r * RP + 4 * q);
+            const f4 vi = *reinterpret_cast<const f4*>(aim_w + ri * RP + 4 * q);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { zr[4 * q + e] = vr[e]; zi[4 * q + e] = has_im ? vi[e] : 0.0f; }
         }
@@ -320,15 +327,14 @@ fe400_kernel(Fe400Args a) {
             }
         }
     }
-    FE_STAMP(5);
-    __syncthreads();                                    // every row is in registers: the row buffers are free
-    FE_STAMP(6);
+    FE_STAMP(3);
+    // (no barrier: the wave's power rows go over its OWN real rows, all of which are in its registers by now)
     // power tile: bin k1 + 25 k2 directly for k2 <= 7 (and 200 = 0 + 25 * 8); the bins with residue 13..24 are the
     // mirror images 400 - k of the outputs with k2 >= 8 (hermitian symmetry, fe_dft400.h bin_of)
     float pmax = NEG_INF, pmin = POS_INF;
     const bool frame_ok = row_ok && (f0 + g3 >= 0) && (f0 + g3 < F);
     if (row_ok) {
-        float* pg = Pt + g3 * NB;
+        float* pg = Pt + g3 * PP;
 #pragma unroll
         for (int k2 = 0; k2 < 8; ++k2) pg[k13 + 25 * k2] = pw[k2];
         if (k13 == 0) pg[200] = pw[8];
@@ -348,19 +354,18 @@ fe400_kernel(Fe400Args a) {
             }
         }
     }
-    if (tid < 16) Pt[G * NB + tid] = 0.0f;              // pad behind the last row: the mel loop reads past a row's end
 
     // ---------------- sparse mel: weights beyond the filter's own count are zeroed (the loads above clamp their index)
 #pragma unroll
     for (int j = 0; j < 14; ++j) mw_[j] = j < mcnt ? mw_[j] : 0.0f;
     if constexpr (STATS) {
         float mmax = NEG_INF, mmin = POS_INF;
-        FE_STAMP(7);
+        FE_STAMP(4);
         __syncthreads();                                // power tile complete
-        FE_STAMP(8);
+        FE_STAMP(5);
         if (mg < 3) {
             for (int gg = mg; gg < G; gg += 3) {
-                const float acc = mel_dot(Pt + gg * NB + ms, mw_);
+                const float acc = mel_dot(Pt + gg * PP + ms, mw_);
                 if (f0 + gg < F) { mmax = fmaxf(mmax, acc); mmin = fminf(mmin, acc); }
                 if (f0 + gg == 0) a.mel0[(size_t)b * NM + mm] = acc;
             }
@@ -381,42 +386,42 @@ fe400_kernel(Fe400Args a) {
             float* s = a.stats + ((size_t)b * a.nt1 + blockIdx.x) * 8;
             s[0] = pmax; s[1] = pmin; s[2] = mmax; s[3] = mmin; s[4] = asum;
         }
-        FE_STAMP(9);
+        FE_STAMP(6);
         return;
     } else {
-        float* const Mc = xs;                           // [G][80]  clipped mel dB (the samples are consumed)
+        float* const Mc = Aim + G * NC + G * NM;        // [G][80]  clipped mel dB
         float* const Mf = Aim;                          // [G][40]  scaled cepstra
         float* const SD = Aim + G * NC;                 // [G][80]  j < 40: m[j] + m[79-j], j >= 40: m[j-40] - m[119-j]
-        FE_STAMP(7);
+        FE_STAMP(4);
         __syncthreads();                                // power tile + constants
-        FE_STAMP(8);
+        FE_STAMP(5);
         const float offp = sc[0], pfloor = sc[1], pS = sc[2], pM = sc[8], offm = sc[3], mfloor = sc[4], mS = sc[5], mM = sc[6],
                     c00 = sc[7];
         const int nvalid = min(GO, F - fo);             // output frames that exist
         const int nrows = min(GO, a.max_frames - fo);   // output rows of the buffers (the rest of them: zeros)
 
-        // ---------------- P_dB: rows 1..14 of the tile are contiguous (pitch 201 = row length)
-        {
-            float* o = a.pow_db + (row0 + fo) * NB;
-            const float* p = Pt + NB;
-            const int tv = nvalid * NB, tr = nrows * NB;
+        // ---------------- P_dB: thread k < 201 walks column k of tile rows 1..14 (every LDS address an immediate, the
+        // global stores of a wave are consecutive floats)
+        if (tid < NB) {
+            float* o = a.pow_db + (row0 + fo) * NB + tid;
+            const float* p = Pt + PP + tid;
             const bool clip = a.clip != 0;
-#pragma unroll 4
-            for (int i = tid; i < tr; i += NT) {
-                float w = pS * (pow_db_clipped(p[i], offp, pfloor) - pM);
+#pragma unroll
+            for (int gg = 0; gg < GO; ++gg) {
+                float w = pS * (pow_db_clipped(p[gg * PP], offp, pfloor) - pM);
                 if (clip) w = fminf(fmaxf(w, -1.0f), 1.0f);
-                o[i] = i < tv ? w : 0.0f;
+                if (gg < nrows) o[gg * NB] = gg < nvalid ? w : 0.0f;
             }
         }
-        FE_STAMP(9);
+        FE_STAMP(6);
         // ---------------- mel power -> dB of the "amplitude" (quirk) -> top_db clip: all 16 frames (DCT halo)
         if (mg < 3) {
             for (int gg = mg; gg < G; gg += 3) {
-                Mc[gg * NM + mm] = mel_db_clipped(mel_dot(Pt + gg * NB + ms, mw_), offm, mfloor);
+                Mc[gg * NM + mm] = mel_db_clipped(mel_dot(Pt + gg * PP + ms, mw_), offm, mfloor);
             }
         }
         __syncthreads();
-        FE_STAMP(10);
+        FE_STAMP(7);
         // ---------------- M_dB out (float4 rows) and the sum / difference halves for the DCT
         {
             const bool clip = a.clip != 0;
@@ -439,7 +444,7 @@ fe400_kernel(Fe400Args a) {
             }
         }
         __syncthreads();
-        FE_STAMP(11);
+        FE_STAMP(8);
         // ---------------- DCT-II: coefficient ci (even: sums, odd: differences), frames cf, cf + 6, cf + 12
         if (tid < 240) {
             const float norm = a.mfcc_norm;
@@ -459,7 +464,7 @@ fe400_kernel(Fe400Args a) {
             }
         }
         __syncthreads();
-        FE_STAMP(12);
+        FE_STAMP(9);
         // ---------------- [MFCC | delta] out (audio_lib.py:226-228, 238): delta = 2 (M[t+1] - M[t-1]), 0 at both ends
         {
             const bool clip = a.clip != 0;
@@ -486,7 +491,7 @@ fe400_kernel(Fe400Args a) {
                 o[i] = v;
             }
         }
-        FE_STAMP(13);
+        FE_STAMP(10);
     }
 }
 

@@ -19,10 +19,11 @@ a256 = lambda v: (v + 255) // 256 * 256
 o_stats = a256(B * 16 * 4)
 o_mel = a256(o_stats + B * nt1 * 8 * 4)
 out = None
-names1 = ['entry->loads landed', 'barrier 1', 'step 1 (25-pt DFT, twiddle, row stores)', 'barrier 2', 'step 3 (16-pt DFT, |.|^2)',
-          'barrier 3', 'power tile + mel weights', 'barrier 4', 'mel + reduce + record']
-names2 = ['entry->loads landed', 'barrier 1', 'step 1', 'barrier 2', 'step 3', 'barrier 3', 'power tile + constants', 'barrier 4',
-          'P_dB out', 'mel dB + barrier', 'M_dB out + sum/diff + barrier', 'DCT + barrier', 'MFCC / delta out']
+names1 = ['entry -> own samples in LDS (wave 0)', '25-point stage, twiddle, row stores', '16-point stage, |.|^2', 'power rows + weights',
+          'barrier (power tile complete)', 'mel + reduce + record']
+names2 = ['entry -> own samples in LDS (wave 0, incl. the utterance constants)', '25-point stage', '16-point stage', 'power rows',
+          'barrier (power tile complete)', 'P_dB out', 'mel dB + barrier', 'M_dB out + sum/diff + barrier', 'DCT + barrier',
+          'MFCC / delta out']
 for mask, nblk, names in ((2, nt1, names1), (4, (mf + 13) // 14, names2)):
     for _ in range(3):
         out = audio_lib.calc_MFCC_input_batch(wav, None, out=out, stage_mask=mask, **kw)
