@@ -396,6 +396,15 @@ gru_mfma_pack_kernel(const __bf16* W0, const __bf16* W1, __bf16* packed) {
     }
 }
 
+// -DVC_ABLATE builds only: per-phase cycle sums of the MFMA recurrence (wave 0 of workgroup (0, 0); s_memtime around
+// the phases of every step), read back with vc_ablate_read_stamps.  The shipped library contains none of this.
+#ifdef VC_ABLATE
+__device__ unsigned long long g_gru_stamps[16];
+#define GRU_T(i) do { if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_t[i] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+#define GRU_T(i) do { } while (0)
+#endif
+
 template <int H>
 __global__ void __launch_bounds__(512, 2)
 gru_mfma_kernel(GruArgs a, const __bf16* packed) {
@@ -449,6 +458,10 @@ gru_mfma_kernel(GruArgs a, const __bf16* packed) {
 
     const __bf16* hrow = hb + n * PITCH + 8 * q;                 // B-fragment source of this lane
     const __bf16* rrow = rhb + n * PITCH + 8 * q;
+#ifdef VC_ABLATE
+    const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+#endif
     for (int step = 0; step < a.T; ++step, t += dt) {
         const bool more = step + 1 < a.T;
         const float* xn = xbase + (size_t)(more ? t + dt : t) * xrow;
@@ -473,6 +486,7 @@ gru_mfma_kernel(GruArgs a, const __bf16* packed) {
                 au[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wg[(1 * TPW + tl) * KSN + ks], bfr[ks], au[tl], 0, 0, 0);
             }
         }
+        GRU_T(0);                                                    // h fragments read, 32 gate MFMAs issued
         float uu[TPW][4];
 #pragma unroll
         for (int tl = 0; tl < TPW; ++tl) {
@@ -486,7 +500,9 @@ gru_mfma_kernel(GruArgs a, const __bf16* packed) {
             }
             *reinterpret_cast<bf16x4v*>(rhb + n * PITCH + ucol + tl * 16) = o;
         }
+        GRU_T(1);                                                    // MFMA results waited for, sigmoids, r*h stored
         __syncthreads();
+        GRU_T(2);                                                    // barrier A
         // ---- phase 2: candidate, state update
 #pragma unroll
         for (int ks = 0; ks < KSN; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8v*>(rrow + ks * 32);
@@ -504,6 +520,7 @@ gru_mfma_kernel(GruArgs a, const __bf16* packed) {
                 ac[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bfr[ks], ac[tl], 0, 0, 0);
             }
         }
+        GRU_T(3);                                                    // r*h fragments read, 16 candidate MFMAs issued
 #pragma unroll
         for (int tl = 0; tl < TPW; ++tl) {
             typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
@@ -524,8 +541,16 @@ gru_mfma_kernel(GruArgs a, const __bf16* packed) {
                 else *reinterpret_cast<f32x4m*>(reinterpret_cast<float*>(a.out) + oi) = hv;
             }
         }
+        GRU_T(4);                                                    // MFMA results waited for, tanh, update, stores issued
         __syncthreads();
+        GRU_T(5);                                                    // barrier B
     }
+#ifdef VC_ABLATE
+    if (stamp) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_gru_stamps[i] = acc_t[i];
+    }
+#endif
 }
 
 template <int H>
@@ -733,6 +758,14 @@ int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw,
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }
+
+#ifdef VC_ABLATE
+int vc_ablate_read_gru_stamps(unsigned long long* h_out) {
+    VC_HIP_CHECK(hipDeviceSynchronize());
+    VC_HIP_CHECK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_gru_stamps), sizeof(unsigned long long) * 16));
+    return VC_OK;
+}
+#endif
 
 int vc_lstm_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw, int32_t w_dtype, int32_t n_seq, int32_t T,
                   int32_t H, void* d_out, int32_t out_dtype, void* stream) {

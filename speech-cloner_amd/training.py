@@ -138,6 +138,8 @@ class StageTrainer:
         self.seed = int(c.get('dropout_seed', 1234))
         self.keep = 1.0 - float(c['dropout_rate'])
         self.loss_ws = torch.empty(256, dtype=torch.float32, device=dev)
+        self._pending = []                           # gradient buckets already being all-reduced (data parallel)
+        self.overlap_allreduce = True                # False: one blocking all-reduce in apply_gradients (tests)
         self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
 
     def load_slots(self, ckpt):
@@ -448,12 +450,40 @@ class StageTrainer:
             dX0 = self._dgrad_dense(dZ1, E, E, W1p, M, T_)
         return dX0
 
+    def _slice_of(self, prefix):
+        """[lo, hi) of the arena covered by the variables under ``prefix`` (contiguous: creation order)."""
+        offs = [self.offsets[n] for n in self.names if n.startswith(prefix)]
+        lo = min(o for o, _, _ in offs)
+        hi = max(o + k for o, k, _ in offs)
+        assert hi - lo == sum(k for _, k, _ in offs), 'variables of %s are not contiguous in the arena' % prefix
+        return lo, hi
+
+    def _start_allreduce(self, lo, hi):
+        """Data parallel: start summing grad[lo:hi] over the ranks NOW (asynchronously: the process group runs it on its
+        own stream behind everything already queued on this one), so that it travels while the rest of the backward
+        pass computes.  apply_gradients() waits for the buckets before Adam reads the arena."""
+        torch = _torch()
+        if not self.overlap_allreduce or not (torch.distributed.is_available() and torch.distributed.is_initialized()) \
+                or torch.distributed.get_world_size() < 2:
+            return
+        self._pending.append((lo, hi, torch.distributed.all_reduce(self.grad[lo:hi], op=torch.distributed.ReduceOp.SUM,
+                                                                    async_op=True)))
+
     def apply_gradients(self, world=1):
-        """All-reduce (data parallel), Adam, bookkeeping.  decoder.py:236-246 / encoder.py:171-181."""
+        """All-reduce (data parallel), Adam, bookkeeping.  decoder.py:236-246 / encoder.py:171-181.  Buckets that
+        forward_backward already put on the wire are waited for; whatever they do not cover is summed here."""
         torch = _torch()
         c = self.cfg
         if world > 1:
-            torch.distributed.all_reduce(self.grad, op=torch.distributed.ReduceOp.SUM)
+            pending, self._pending = self._pending, []
+            covered = sorted((lo, hi) for lo, hi, _ in pending)
+            pos = 0
+            for lo, hi in covered + [(self.total, self.total)]:
+                if lo > pos:                                  # a stretch no bucket covered
+                    torch.distributed.all_reduce(self.grad[pos:lo], op=torch.distributed.ReduceOp.SUM)
+                pos = max(pos, hi)
+            for _, _, work in pending:
+                work.wait()
         self.step_count += 1
         t = self.step_count
         lr = float(self.dec.opt_state[self.opt_scope + '/learning_rate'])
@@ -521,10 +551,13 @@ class DecoderTrainer(StageTrainer):
                 dY2.mul_(1.0 / ls)
             dX2 = self._stage_backward(s2, sv2, dY2, need_dx=True)
             del sv2
+            # stage 2's gradients (22.5 M of the 33.2 M floats) are final: their all-reduce runs under stage 1's backward
+            self._start_allreduce(*self._slice_of(s2 + '/'))
             # y_mel feeds step 2 (decoder.py:155; through the blend with weight f_mel_pred when teacher-forced, :152)
             _vc.check(_lib().vc_axpby(_p(dY1), dY1.shape[1], 1.0, _p(dX2), dX2.shape[1], f_mel, _p(dY1), dY1.shape[1], M,
                                       dY1.shape[1], _st()))
             self._stage_backward(s1, sv1, dY1, need_dx=False)
+            self._start_allreduce(*self._slice_of(s1 + '/'))
         return self.losses
 
 

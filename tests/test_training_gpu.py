@@ -379,13 +379,18 @@ def batch(r):
     return ppg, g.uniform(0, 0.8, (4, 40, 80)).astype(np.float32), g.uniform(0, 0.8, (4, 40, 201)).astype(np.float32)
 tr = dec._get_trainer()
 mine = batch(rank)
+tr.overlap_allreduce = False                    # this rank's own gradient, nothing on the wire yet
 tr.forward_backward(*(torch.from_numpy(a).cuda() for a in mine))
 g_local = tr.grad.clone()
 p_before = tr.flat.clone()
-tr.apply_gradients(world)                       # all-reduce + Adam with grad_scale 1/world
+tr.overlap_allreduce = True                     # the shipped form: stage 2's bucket travels under stage 1's backward
+tr.forward_backward(*(torch.from_numpy(a).cuda() for a in mine))
+assert len(tr._pending) == 2, tr._pending
+tr.apply_gradients(world)                       # waits for the buckets; Adam with grad_scale 1/world
 # reference on every rank: the other rank's gradient computed locally with identical weights/seeds
 dec2, _, _, _, _ = _setup(_cfg())
 tr2 = dec2._get_trainer()
+tr2.overlap_allreduce = False
 other = batch(1 - rank)
 tr2.forward_backward(*(torch.from_numpy(a).cuda() for a in other))
 total = g_local + tr2.grad
