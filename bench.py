@@ -675,10 +675,14 @@ def main(argv=None):
     if world != args.gpus:
         raise SystemExit('bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE)' % (args.gpus, world))
     stub = args.workload == 'stub'
+    backend_arg = args.backend
     if not stub:
         if not torch.cuda.is_available():
             raise SystemExit('bench.py needs a GPU')
-        torch.cuda.set_device(local)
+        ndev = torch.cuda.device_count()
+        if local >= ndev and backend_arg != 'gloo':
+            raise SystemExit('bench.py: rank %d has no GPU of its own (%d visible); RCCL needs one device per rank' % (local, ndev))
+        torch.cuda.set_device(local % ndev)             # (ranks share a card only in gloo rehearsals on a one-GPU box)
     backend = args.backend or ('gloo' if stub else 'nccl')
     dist_util.init(backend)
     joined = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1

@@ -100,6 +100,33 @@ def test_config2_full_size_properties():
             _cmp(t[b].cpu().numpy(), r, TOL[name], '%s[%d]' % (name, b))
 
 
+def test_ragged_tile_edges_and_narrow_dynamic_range():
+    """The two-launch path of the shipped configuration at its seams: utterances whose frame counts sit on and around
+    the 14-frame feature tiles and the 16-frame statistics tiles (F = 3, 14, 15, 16, 17, 29), the shortest legal one, and
+    white noise -- whose spectrum spans far less than top_db = 80 dB, so the min shift acts on the TRUE minimum (not the
+    floor) and must still map it to exactly 0, as `x - x.min()` does in the reference (audio_lib.py:230-235)."""
+    import torch
+    import audio_lib
+    rng = np.random.RandomState(11)
+    lens = [201, 1119, 1120, 1279, 1280, 2319, 8000]
+    L = max(lens)
+    wav = np.zeros((len(lens), L), np.float32)
+    for b, n in enumerate(lens):
+        wav[b, :n] = rng.standard_normal(n).astype(np.float32) * (0.01 + 0.3 * b)
+    mfcc, mel, pdb = audio_lib.calc_MFCC_input_batch(torch.from_numpy(wav).cuda(), lens, **FE_KW)
+    Fmax = 1 + L // 80
+    for b, n in enumerate(lens):
+        F = 1 + n // 80
+        ref = fo.calc_MFCC_input(wav[b, :n], **FE_KW)
+        for name, t, r in zip(('mfcc', 'mel', 'pdb'), (mfcc, mel, pdb), ref):
+            _cmp(t[b, :F].cpu().numpy(), r, TOL[name], '%s len %d' % (name, n))
+            if F < Fmax:
+                assert float(t[b, F:].abs().max()) == 0.0
+        assert float(pdb[b, :F].min()) == 0.0 and float(mel[b, :F].min()) == 0.0, n      # exact, floor or not
+        assert float(ref[1].min()) == 0.0 and float(ref[1].max()) < 0.6     # the oracle agrees: the mel range is far inside 80 dB
+        assert float(mfcc[b, 0, 0]) == 0.0
+
+
 def test_errors_are_loud():
     import torch
     import _vc
