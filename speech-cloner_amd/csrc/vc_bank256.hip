@@ -60,7 +60,7 @@ bank256_kernel(Bank256Args a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);      // provably wave-uniform
-    const int wr = wid >> 2, wc = wid & 3;             // wave tile: rows wr*128.., cols wc*64..
+    const int wr = wid >> 2, wc = wid & 3;             // wave tile: rows wr*128.., cols wc*64.. (wc < 2: the narrower filter)
     // Block -> (pair, row tile).  XCD-aware form: workgroup ids go round-robin to the 8 XCDs, so id & 7
     // names the XCD; the launcher gives every XCD a short list of (pair, row-tile range) segments so that a
     // pair's weight stream (up to 4 MB) is fetched into one or two L2s instead of eight (see vc_launch_bank256).
@@ -122,14 +122,16 @@ bank256_kernel(Bank256Args a) {
     };
     auto stageB = [&](int n, int buf) {
         const int cs = n / ntap, j = n - cs * ntap;
-        // At the wider filter's extra tap the narrower one has no weights: its half of the tile is
-        // filled with its LAST tap again.  Those waves multiply zeroed activations there, and the
-        // zeros need finite partners (stale LDS bytes may decode to Inf/NaN: 0 * Inf = NaN).
+        // At the wider filter's extra tap the narrower one has no weights: its half of the tile is not
+        // fetched and its waves skip the tile's products (tile(), `active`).  (Multiplying zeroed activations
+        // with whatever the buffer held there turned stale Inf/NaN bytes into NaN once; and the skipped
+        // products are worth 1.5-1.9 % of the launch: profiles/r02/ab_bank_skip_extra_tap.log.)
         const int koffR = j * a.Cin + cs * 64;
         const int koffL = min(j, pr.taps0 - 1) * a.Cin + cs * 64;
         char* dst = Bs + buf * B_BYTES + wid * 1024;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) glds16(b_src[q] + (q < 2 ? koffL : koffR), dst + q * 8192);
+        for (int q = 0; q < 4; ++q)
+            if (q >= 2 || j < pr.taps0) glds16(b_src[q] + (q < 2 ? koffL : koffR), dst + q * 8192);
     };
 
     // ---------------- MFMA roles
@@ -212,9 +214,23 @@ bank256_kernel(Bank256Args a) {
     // one K tile (4 k-steps of 8 MFMAs); MASK = some row of this wave sees SAME padding at this tap
     auto tile = [&](int n, const bool need_mask) {
         const bool active = !(left_wave && j >= pr.taps0);     // the narrower filter has no tap taps0
+        if (!active) {
+            // nothing to multiply: keep the tile's one barrier and this wave's share of the staging, then fetch the
+            // next tile's first fragments (wave-uniform branch)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (n + 2 < ntiles) stageB(n + 2, n & 1);
+            if (n + 1 < ntiles) {
+                const int cs1 = (n + 1) / ntap;
+                if ((n + 1) - cs1 * ntap == 0 && cs1 + 1 < nslab) stageA(cs1 + 1, (cs1 + 1) & 1);
+                j = tap_setup(n + 1);
+                load_frags(0, 0, (n + 1) & 1);
+            }
+            return;
+        }
         bool v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = active && j >= jlo[i] && j < jhi[i];
+        for (int i = 0; i < 4; ++i) v[i] = j >= jlo[i] && j < jhi[i];
         const bf16x8 zero = {};
         int jn = j;
 #pragma unroll
