@@ -119,17 +119,22 @@ size_t vc_frontend_workspace_bytes(const vc_frontend_plan* plan, int32_t batch, 
  *   d_wav      float32 [batch, wav_stride]   (utterance b = row b, first lens[b] samples)
  *   d_lens     int32   [batch] sample counts, or NULL => every utterance has max_samples
  *              (each must satisfy n_fft/2 < len <= max_samples)
- *   max_frames = 1 + max_samples / hop_length = row count of the outputs
- *   d_mfcc     float32 [batch, max_frames, mfcc_width]
- *   d_mel_db   float32 [batch, max_frames, n_mels]
- *   d_pow_db   float32 [batch, max_frames, 1 + n_fft/2]
+ *   max_frames = 1 + max_samples / hop_length
+ *   out_rows   row count of the outputs per utterance: 0 = max_frames; a smaller value stores only the first out_rows
+ *              frames (the later ones still count for the utterance's normalisation statistics, as in the reference,
+ *              which computes the whole utterance and then cuts windows: /root/reference/test.py:121-123, 240-241) -- e.g.
+ *              800 for 4 s at hop 80, so that [batch, 800, n_mels] IS the [2 * batch, 400, n_mels] window batch of the
+ *              encoder without a copy.  Needs the two-pass 400-point path when < max_frames.
+ *   d_mfcc     float32 [batch, out_rows, mfcc_width]
+ *   d_mel_db   float32 [batch, out_rows, n_mels]
+ *   d_pow_db   float32 [batch, out_rows, 1 + n_fft/2]
  *              rows f >= 1 + lens[b]/hop of utterance b are zero-filled.
  *   d_workspace / workspace_bytes: scratch of at least vc_frontend_workspace_bytes().
  * Two launches on `stream`: STFT power + mel + raw dB with per-tile max / min / sum|x| partials;
  * finalize (amplitude normalisation as a dB offset, amin and top_db clips, min shift, DCT, delta,
  * clip).  With hop_length > n_fft/2 a third launch computes the per-utterance sum|x| first. */
 int vc_frontend_f32(const vc_frontend_plan* plan, const float* d_wav, const int32_t* d_lens,
-                    int32_t batch, int32_t max_samples, int32_t wav_stride,
+                    int32_t batch, int32_t max_samples, int32_t wav_stride, int32_t out_rows,
                     float* d_mfcc, float* d_mel_db, float* d_pow_db,
                     void* d_workspace, size_t workspace_bytes, void* stream);
 
@@ -137,7 +142,7 @@ int vc_frontend_f32(const vc_frontend_plan* plan, const float* d_wav, const int3
  * one kernel with HIP events): stage_mask bit0 = |x| partial sums (a launch only when
  * hop_length > n_fft/2), bit1 = STFT power/mel/dB, bit2 = finalize.  Later stages read what earlier ones left in the workspace. */
 int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, const int32_t* d_lens,
-                           int32_t batch, int32_t max_samples, int32_t wav_stride,
+                           int32_t batch, int32_t max_samples, int32_t wav_stride, int32_t out_rows,
                            float* d_mfcc, float* d_mel_db, float* d_pow_db,
                            void* d_workspace, size_t workspace_bytes, void* stream,
                            int32_t stage_mask);

@@ -109,9 +109,9 @@ _SIGS = {
     'vc_frontend_get_mel': (C.c_int, [_P, _P]),
     'vc_frontend_get_dct': (C.c_int, [_P, _P]),
     'vc_frontend_workspace_bytes': (C.c_size_t, [_P, C.c_int32, C.c_int32]),
-    'vc_frontend_f32': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P,
+    'vc_frontend_f32': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P,
                                   C.c_size_t, _P]),
-    'vc_frontend_stages_f32': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P,
+    'vc_frontend_stages_f32': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P,
                                          C.c_size_t, _P, C.c_int32]),
     'vc_conv_gemm': (C.c_int, [C.POINTER(GemmDesc), _P]),
     'vc_softmax_argmax': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),

@@ -95,15 +95,19 @@ def calc_MFCC_input_batch(wav, lens=None,
                           mean_abs_amp_norm=0.003,
                           clip_output=True,
                           out=None,
-                          stage_mask=7):
+                          stage_mask=7,
+                          out_frames=None):
     """Batched calc_MFCC_input on the GPU.
 
     wav  : float32 [B, L] torch.cuda tensor (or numpy array, uploaded).
     lens : optional per-utterance sample counts (sequence / int32 tensor); None = all L.
     out  : optional (mfcc, mel, pow) preallocated cuda tensors to write into.
     stage_mask : measurement hook (bench.py): subset of the three launches, see vc_hip.h.
-    Returns (MFCC [B, Fmax, W], M_dB [B, Fmax, n_mels], P_dB [B, Fmax, 1+n_fft//2]) cuda float32
-    with Fmax = 1 + L//hop_length; rows beyond an utterance's own frame count are zero."""
+    out_frames : store only the first out_frames frames of every utterance (the later ones still count for its
+                 normalisation statistics): with out_frames a multiple of the window length the result reshapes to the
+                 encoder's window batch without a copy.  None = all Fmax = 1 + L//hop_length frames.
+    Returns (MFCC [B, R, W], M_dB [B, R, n_mels], P_dB [B, R, 1+n_fft//2]) cuda float32, R = out_frames or Fmax;
+    rows beyond an utterance's own frame count are zero."""
     import torch
     if not torch.cuda.is_available():
         raise _vc.VCError('calc_MFCC_input needs a GPU (no CPU fallback)')
@@ -127,14 +131,20 @@ def calc_MFCC_input_batch(wav, lens=None,
                 raise ValueError(' - ERROR, calc_MFCC_input_batch: lens must be [B] with n_fft//2 < len <= L')
             d_lens = torch.from_numpy(h).to('cuda')
     Fmax = 1 + L // plan.cfg.hop_length
+    R = Fmax if out_frames is None else int(out_frames)
+    if not 0 < R <= Fmax:
+        raise ValueError(' - ERROR, calc_MFCC_input_batch: out_frames must be in [1, {}]'.format(Fmax))
     if out is None:
-        mfcc = torch.empty((B, Fmax, plan.mfcc_width), dtype=torch.float32, device=wav.device)
-        mel = torch.empty((B, Fmax, plan.cfg.n_mels), dtype=torch.float32, device=wav.device)
-        pdb = torch.empty((B, Fmax, plan.n_bins), dtype=torch.float32, device=wav.device)
+        mfcc = torch.empty((B, R, plan.mfcc_width), dtype=torch.float32, device=wav.device)
+        mel = torch.empty((B, R, plan.cfg.n_mels), dtype=torch.float32, device=wav.device)
+        pdb = torch.empty((B, R, plan.n_bins), dtype=torch.float32, device=wav.device)
     else:
         mfcc, mel, pdb = out
+        for t, w in ((mfcc, plan.mfcc_width), (mel, plan.cfg.n_mels), (pdb, plan.n_bins)):
+            if tuple(t.shape) != (B, R, w) or not t.is_contiguous() or t.dtype != torch.float32:
+                raise ValueError(' - ERROR, calc_MFCC_input_batch: out tensors must be contiguous float32 [B, {}, width]'.format(R))
     ws = plan.workspace(B, L, wav.device)
-    _vc.check(_vc.lib().vc_frontend_stages_f32(plan.handle, _vc.ptr(wav), _vc.ptr(d_lens), B, L, wav.stride(0),
+    _vc.check(_vc.lib().vc_frontend_stages_f32(plan.handle, _vc.ptr(wav), _vc.ptr(d_lens), B, L, wav.stride(0), R,
                                                _vc.ptr(mfcc), _vc.ptr(mel), _vc.ptr(pdb),
                                                _vc.ptr(ws), ws.numel(), _vc.current_stream(),
                                                int(stage_mask)))

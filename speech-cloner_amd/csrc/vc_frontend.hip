@@ -777,7 +777,7 @@ size_t vc_frontend_workspace_bytes(const vc_frontend_plan* plan, int32_t batch, 
 }
 
 int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, const int32_t* d_lens, int32_t batch,
-                           int32_t max_samples, int32_t wav_stride, float* d_mfcc, float* d_mel_db, float* d_pow_db,
+                           int32_t max_samples, int32_t wav_stride, int32_t out_rows, float* d_mfcc, float* d_mel_db, float* d_pow_db,
                            void* d_workspace, size_t workspace_bytes, void* stream, int32_t stage_mask) {
     VC_REQUIRE(plan && d_wav && d_mfcc && d_mel_db && d_pow_db && d_workspace, "NULL argument");
     VC_REQUIRE(batch > 0 && batch <= 65535, "batch out of range: %d", batch);
@@ -786,12 +786,17 @@ int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, con
     size_t o_partial, o_stats, o_mel, total; int ntiles, max_frames;
     ws_layout(plan, batch, max_samples, &o_partial, &o_stats, &o_mel, &total, &ntiles, &max_frames);
     if (workspace_bytes < total) return vc::set_error(VC_ERR_WORKSPACE, "workspace too small: %zu < %zu", workspace_bytes, total);
+    if (out_rows == 0) out_rows = max_frames;
+    VC_REQUIRE(out_rows > 0 && out_rows <= max_frames, "out_rows (%d) must be in [1, %d]", out_rows, max_frames);
+    VC_REQUIRE(plan->fast400 || out_rows == max_frames,
+               "out_rows < max_frames needs the two-pass 400-point front-end (n_fft 400, hop 80, 80 mels, 40 cepstra)");
 
     const vc_frontend_cfg& c = plan->cfg;
     if (plan->fast400) {
         // shipped configuration: statistics pass + feature pass, every output byte written once (vc_frontend400.hip)
         Fe400Args f;
         f.wav = d_wav; f.lens = d_lens; f.max_samples = max_samples; f.wav_stride = wav_stride; f.max_frames = max_frames;
+        f.out_rows = out_rows;
         f.win_tw = plan->dev.window;                    // window[400] | tw400[416] are adjacent in the blob
         f.mel_w = plan->dev.mel_w; f.mel_start = plan->dev.mel_start; f.mel_off = plan->dev.mel_off;
         f.dct_half = plan->d_dct_half;
@@ -861,9 +866,9 @@ int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, con
 }
 
 int vc_frontend_f32(const vc_frontend_plan* plan, const float* d_wav, const int32_t* d_lens, int32_t batch,
-                    int32_t max_samples, int32_t wav_stride, float* d_mfcc, float* d_mel_db, float* d_pow_db,
+                    int32_t max_samples, int32_t wav_stride, int32_t out_rows, float* d_mfcc, float* d_mel_db, float* d_pow_db,
                     void* d_workspace, size_t workspace_bytes, void* stream) {
-    return vc_frontend_stages_f32(plan, d_wav, d_lens, batch, max_samples, wav_stride, d_mfcc, d_mel_db, d_pow_db,
+    return vc_frontend_stages_f32(plan, d_wav, d_lens, batch, max_samples, wav_stride, out_rows, d_mfcc, d_mel_db, d_pow_db,
                                   d_workspace, workspace_bytes, stream, 7);
 }
 

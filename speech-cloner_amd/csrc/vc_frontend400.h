@@ -8,6 +8,7 @@ struct Fe400Args {
     const float* wav;
     const int32_t* lens;
     int32_t max_samples, wav_stride, max_frames;
+    int32_t out_rows;             // rows per utterance of mfcc / mel_db / pow_db (<= max_frames): later frames only feed the statistics
     const float* win_tw;          // window[400] | W400^(n2 k1) cos [13][16] | sin [13][16]   (16-byte aligned)
     const float* mel_w;           // sparse Slaney rows, <= 14 weights each
     const int32_t* mel_start;     // [80]

@@ -117,7 +117,7 @@ fe400_kernel(Fe400Args a) {
     // first transformed frame of the tile (pass 2: one halo frame ahead of the first output frame)
     const int fo = (STATS ? G : GO) * (int)blockIdx.x;          // first frame this block is responsible for
     const int f0 = STATS ? fo : fo - 1;
-    const size_t row0 = (size_t)b * a.max_frames;
+    const size_t row0 = (size_t)b * a.out_rows;          // the output arrays hold out_rows <= max_frames rows per utterance
 
     if (fo >= F) {
         if constexpr (STATS) {
@@ -126,7 +126,7 @@ fe400_kernel(Fe400Args a) {
                 s[0] = NEG_INF; s[1] = POS_INF; s[2] = NEG_INF; s[3] = POS_INF; s[4] = 0.0f;
             }
         } else {                                        // padding rows of a ragged batch: zeros
-            const int nrows = min(GO, a.max_frames - fo);
+            const int nrows = min(GO, a.out_rows - fo);
             const int mw = a.deriv ? 2 * NC : NC;
             float* o1 = a.mfcc + (row0 + fo) * mw;
             float* o2 = a.mel_db + (row0 + fo) * NM;
@@ -398,7 +398,7 @@ fe400_kernel(Fe400Args a) {
         const float offp = sc[0], pfloor = sc[1], pS = sc[2], pM = sc[8], offm = sc[3], mfloor = sc[4], mS = sc[5], mM = sc[6],
                     c00 = sc[7];
         const int nvalid = min(GO, F - fo);             // output frames that exist
-        const int nrows = min(GO, a.max_frames - fo);   // output rows of the buffers (the rest of them: zeros)
+        const int nrows = min(GO, a.out_rows - fo);     // output rows of the buffers (the rest of them: zeros); <= 0 past out_rows
 
         // ---------------- P_dB: thread k < 201 walks column k of tile rows 1..14 (every LDS address an immediate, the
         // global stores of a wave are consecutive floats)
@@ -502,7 +502,7 @@ int vc_fe400_launch(const Fe400Args& a, int batch, int stage_mask, hipStream_t s
     if (stage_mask & 2)
         hipLaunchKernelGGL(fe400_kernel<true>, dim3(a.nt1, batch), dim3(NT), lds, st, a);
     if (stage_mask & 4) {
-        const int nt2 = (a.max_frames + GO - 1) / GO;
+        const int nt2 = (a.out_rows + GO - 1) / GO;    // tiles past the stored rows have nothing to write
         hipLaunchKernelGGL(fe400_kernel<false>, dim3(nt2, batch), dim3(NT), lds, st, a);
     }
     VC_HIP_CHECK(hipGetLastError());

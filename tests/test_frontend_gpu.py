@@ -127,6 +127,36 @@ def test_ragged_tile_edges_and_narrow_dynamic_range():
         assert float(mfcc[b, 0, 0]) == 0.0
 
 
+def test_stored_rows_can_be_fewer_than_the_frames():
+    """out_frames (vc_hip.h out_rows): the first R frames of every utterance, bit-identical to the same rows of the full
+    result -- the frames that are not stored still count for the utterance's max / min / mean|x| (the reference computes
+    the whole utterance, then reshapes to windows: test.py:121-123) -- at R on and off the 14-frame tile grid, ragged
+    batch included; [B, 800, 80] then is the encoder's [2B, 400, 80] window batch without a copy."""
+    import torch
+    import _vc
+    import audio_lib
+    rng = np.random.RandomState(5)
+    lens = [64000, 64000, 40000, 1119, 63999, 64000]
+    wav = np.zeros((len(lens), 64000), np.float32)
+    for b, n in enumerate(lens):
+        wav[b, :n] = rng.standard_normal(n).astype(np.float32) * 0.05 * (b + 1)
+    wav[1, 63960:] *= 40.0                      # utterance 1's maximum sits in frame 800, which R = 800 does not store
+    d = torch.from_numpy(wav).cuda()
+    full = audio_lib.calc_MFCC_input_batch(d, lens, **FE_KW)
+    assert full[0].shape[1] == 801
+    for R in (800, 795, 14, 1):
+        part = audio_lib.calc_MFCC_input_batch(d, lens, out_frames=R, **FE_KW)
+        for name, f, q in zip(('mfcc', 'mel', 'pdb'), full, part):
+            assert q.shape[:2] == (len(lens), R) and q.is_contiguous()
+            assert torch.equal(q, f[:, :R]), (name, R)
+    win = audio_lib.calc_MFCC_input_batch(d, lens, out_frames=800, **FE_KW)[0].view(2 * len(lens), 400, 80)
+    assert win.is_contiguous() and torch.equal(win[3], full[0][1, 400:800])
+    with pytest.raises(ValueError):
+        audio_lib.calc_MFCC_input_batch(d, lens, out_frames=802, **FE_KW)
+    with pytest.raises(_vc.VCError):            # the general-configuration path keeps raw tiles in the outputs: all rows or none
+        audio_lib.calc_MFCC_input_batch(d, lens, out_frames=400, **FE_KW_GENERIC)
+
+
 def test_errors_are_loud():
     import torch
     import _vc
