@@ -87,6 +87,15 @@ __device__ __forceinline__ void hw_tile(const bf16x8* pw, const bf16x8* next, co
     }
 }
 
+// -DVC_ABLATE builds only: cycle sums per phase (s_memtime, thread 0 of workgroup 7), read back with
+// vc_ablate_read_highway_stamps (tools/highway_phase_stamps.py).  The shipped library contains none of this.
+#ifdef VC_ABLATE
+__device__ unsigned long long g_hw_stamps[8];
+#define HW_T(i) do { if (stamp) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); acc_t[i] += t_ - t_prev; t_prev = t_; } } while (0)
+#else
+#define HW_T(i) do { } while (0)
+#endif
+
 template <int H>
 __global__ void __launch_bounds__(2 * H, H == 256 ? 1 : 2)
 highway_chain_kernel(HwChainArgs a) {
@@ -96,6 +105,10 @@ highway_chain_kernel(HwChainArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, lh = lane >> 5, x15 = li & 15;
     const int m0 = blockIdx.x * HW_BM;
+#ifdef VC_ABLATE
+    const bool stamp = blockIdx.x == 7 && tid == 0;
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- activation tile -> LDS buffer 0
     for (int idx = tid; idx < HW_BM * NS; idx += NT) {
@@ -126,6 +139,7 @@ highway_chain_kernel(HwChainArgs a) {
         }
     }
     __syncthreads();
+    HW_T(0);
 
     for (int layer = 0; layer < a.n_layers; ++layer) {
         const char* cur = smem + (layer & 1) * (HW_BM * RB);
@@ -134,6 +148,10 @@ highway_chain_kernel(HwChainArgs a) {
         f32x16 acc[4][2];
         const bf16x8* nextw = more ? wptr(layer + 1, 0) : (a.PW ? reinterpret_cast<const bf16x8*>(a.PW) + ((size_t)w * KS * 2) * 64 + lane : nullptr);
         hw_tile<H>(wptr(layer, 0), nextw, cur + li * RB, lh, x15, wr, acc);
+#ifdef VC_ABLATE
+        if (stamp) asm volatile("" :: "v"(acc[3][1][15]));     // the stamp waits for the last accumulator
+#endif
+        HW_T(1);
         // ---- gate (lane-local) -> next activation tile
         f32x4h bH[4], bT[4];
 #pragma unroll
@@ -155,7 +173,9 @@ highway_chain_kernel(HwChainArgs a) {
                 *reinterpret_cast<bf16x4*>(nxt + off) = o;
             }
         }
+        HW_T(2);
         __syncthreads();
+        HW_T(3);
     }
 
     const char* fin = smem + (a.n_layers & 1) * (HW_BM * RB);
@@ -165,6 +185,8 @@ highway_chain_kernel(HwChainArgs a) {
         constexpr int NW = 2 * H / 64;
         const int ngroups = a.NP / 64;
         const char* xrow = fin + li * RB;
+        char* const stg = smem + ((a.n_layers & 1) ^ 1) * (HW_BM * RB) + w * 8192;    // the other activation buffer is idle
+        static_assert((2 * H / 64) * 8192 <= HW_BM * 2 * H, "a 32 x 64 float32 sub-tile per wave fits the idle buffer");
         if (a.n_layers == 0) {
             const bf16x8* p0 = reinterpret_cast<const bf16x8*>(a.PW) + ((size_t)w * KS * 2) * 64 + lane;
 #pragma unroll
@@ -175,24 +197,48 @@ highway_chain_kernel(HwChainArgs a) {
             const bf16x8* nextw = (grp + NW < ngroups) ? pw + (size_t)NW * KS * 128 : nullptr;
             f32x16 acc[4][2];
             hw_tile<H>(pw, nextw, xrow, lh, x15, wr, acc);
+            // A lane holds one frame and 4 consecutive columns per register quad: stored directly, one instruction
+            // writes 32 rows x 32 B.  The launch's second half is this 786 KB-per-block store stream, so each 32 x 64
+            // sub-tile goes through a wave-private 8 KB of the idle activation buffer (16-byte chunk c of row r at
+            // chunk c ^ (r & 15); LDS operations of one wave execute in order: no barrier) and leaves as 256-byte rows.
 #pragma unroll
-            for (int c = 0; c < 2; ++c) {
+            for (int c = 0; c < 2; ++c)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int n = grp * 64 + c * 32 + 8 * q + 4 * lh;
-                    const f32x4h bb = *reinterpret_cast<const f32x4h*>(a.Pbias + n);
+                    const f32x4h bb = *reinterpret_cast<const f32x4h*>(a.Pbias + grp * 64 + c * 32 + 8 * q + 4 * lh);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int gm = m0 + i * 32 + li;
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][c][4 * q + e] += bb[e];
+                }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
                         f32x4h o;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = acc[i][c][4 * q + e] + bb[e];
-                        if (gm < a.M) *reinterpret_cast<f32x4h*>(a.P + (size_t)gm * a.ldp + n) = o;
+                        for (int e = 0; e < 4; ++e) o[e] = acc[i][c][4 * q + e];
+                        *reinterpret_cast<f32x4h*>(stg + li * 256 + (((c * 8 + 2 * q + lh) ^ x15) << 4)) = o;
                     }
+#pragma unroll 2
+                for (int j = 0; j < 8; ++j) {
+                    const int row = j * 4 + (lane >> 4), ch = lane & 15;
+                    const f32x4h v = *reinterpret_cast<const f32x4h*>(stg + row * 256 + ((ch ^ (row & 15)) << 4));
+                    const int gm = m0 + i * 32 + row;
+                    if (gm < a.M) *reinterpret_cast<f32x4h*>(a.P + (size_t)gm * a.ldp + grp * 64 + ch * 4) = v;
                 }
             }
         }
     }
+    HW_T(4);
+#ifdef VC_ABLATE
+    if (stamp) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_hw_stamps[i] = acc_t[i];
+    }
+#endif
     if (a.Y == nullptr) return;
     // ---- final tile -> global
     for (int idx = tid; idx < HW_BM * NS; idx += NT) {
@@ -244,6 +290,14 @@ int vc_highway_pack(const void* d_Bt, int32_t n_cols, int32_t H, void* d_packed,
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }
+
+#ifdef VC_ABLATE
+int vc_ablate_read_highway_stamps(unsigned long long* h_out) {
+    VC_HIP_CHECK(hipDeviceSynchronize());
+    VC_HIP_CHECK(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_hw_stamps), sizeof(unsigned long long) * 8));
+    return VC_OK;
+}
+#endif
 
 int vc_highway_chain(const void* d_X, int32_t M, int32_t H, int32_t ldx, int32_t n_layers, const void* const* d_packed,
                      const float* const* d_bias, void* d_Y, int32_t ldy, const void* d_proj_packed,

@@ -6,7 +6,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/build/ablate
 cd $R/speech-cloner_amd/csrc
 for f in *.hip; do
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DVC_ABLATE -I$R/include -I. -c $f -o $R/build/ablate/${f%.hip}.o &
+  /opt/rocm/bin/hipcc -O3 -fno-slp-vectorize -std=c++17 -fPIC --offload-arch=gfx950 -DVC_ABLATE -I$R/include -I. -c $f -o $R/build/ablate/${f%.hip}.o &
 done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 $R/build/ablate/*.o -o $R/build/libvc_hip_ablate.so
