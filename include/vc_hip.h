@@ -53,6 +53,8 @@ const char* vc_target_arch(void);
  *   "proj256"        0 = the 256-channel k = 3 projection on conv256_kernel instead of the bank tiles
  *   "wgrad_xcd"      0 = weight-gradient tiles dealt round-robin to the XCDs
  *   "gru_mfma"       0 = VALU recurrence always, 1 = MFMA recurrence always (default: from 32 sequences up)
+ *   "prenet_lds"     0 = every wave of the fused prenet streams the weights from L2 itself (default: one stream per
+ *                    block, shared through LDS)
  *   "cbhg_front_mi"  4 = 128-row blocks in the fused encoder front
  * All alternatives compute the same function (tests compare them).  Three more names, "ablate_bank256",
  * "ablate_bank256_only" and "ablate_cbhg_front", skip parts of a kernel for timing and give WRONG results: they

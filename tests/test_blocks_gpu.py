@@ -489,7 +489,12 @@ def test_prenet_single_launch(N, T, cin, E):
         assert modules._vc.lib().vc_prenet_chain_supported(cp, E, E // 2)
         poison_gpu_state()
         y = modules.prenet(xd, None, E, 0.1, False, in_features=cin)
+        # the form in which every wave streams the weights itself: same products in the same order
+        with modules._vc.options(prenet_lds=0):
+            poison_gpu_state()
+            y_own = modules.prenet(xd, None, E, 0.1, False, in_features=cin)
     torch.cuda.synchronize()
+    assert torch.equal(y, y_own)
     assert y.shape == (N, T, E // 2) and not torch.isnan(y.float()).any()
     d = (y.float() - y_ref.float()).abs()
     assert d.max().item() < 1e-2, d.max().item()
