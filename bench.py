@@ -269,7 +269,7 @@ def bench_full(args, rank, world):
     400-frame windows -> encode + decode, `--window-batch` windows per launch."""
     import audio_lib
     import modules
-    B, L, T = 32, 64000, 400
+    B, L, T = args.batch, 64000, 400
     wav = synth_audio(B, L, seed=rank).cuda()
     enc, dec = load_models(args.dtype, rank)
     nwin = B * 2
@@ -349,9 +349,9 @@ def bench_full(args, rank, world):
                             'steps': k32, 'what': 'same step with float32 weights / activations / accumulation (the '
                                                   "reference's arithmetic type), %d streams" % min(args.streams, 4)}
         del pipe32, enc32, dec32
-    cfg = {'workload': 'full: STFT+mel front-end on batch 32 x 4 s @ 16 kHz (configs[1] input) -> 64 windows of 400 '
+    cfg = {'workload': 'full: STFT+mel front-end on batch %d x 4 s @ 16 kHz (configs[1] input) -> %d windows of 400 '
                        'frames -> encoder (enc_14 weights) + decoder (hp/decoder_cfg_d.json sizes, random init), '
-                       '%d windows per launch, independent steps pipelined over %d HIP streams' % (args.window_batch, args.streams),
+                       '%d windows per launch, independent steps pipelined over %d HIP streams' % (B, nwin, args.window_batch, args.streams),
            'batch': B, 'samples': L, 'windows': nwin, 'frames_per_step_per_gpu': frames, 'model_dtype': args.dtype,
            'streams': args.streams}
     return frames, dt, extra, cfg
@@ -661,6 +661,8 @@ def main(argv=None):
     ap.add_argument('--warmup', type=int, default=6)
     ap.add_argument('--workload', default='full', choices=['full', 'frontend', 'train', 'vocoder', 'stub'])
     ap.add_argument('--dtype', default='bfloat16', choices=['bfloat16', 'float32'])
+    ap.add_argument('--batch', type=int, default=32,
+                    help='utterances per step of the full workload (BASELINE metric: 32; configs[3] reads as 64 -> 128 windows)')
     ap.add_argument('--window-batch', type=int, default=64)
     ap.add_argument('--streams', type=int, default=10,
                     help='HIP streams the independent window chunks / consecutive steps are pipelined over')
