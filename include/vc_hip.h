@@ -327,6 +327,18 @@ int vc_fill(float* d_p, float value, size_t n, void* stream);
 /* out[m][c] = a * X[m][c] + b * Y[m][c] over [M, C] float32 views with row strides ldx / ldy / ldo (out may alias X or
  * Y).  decoder_specs._build_model's teacher-forced stage-2 input, /root/reference/decoder.py:148-152:
  * inputs_step2 = f_mel_pred * y_mel + (1 - f_mel_pred) * target_mel, and its gradient dY_mel += f_mel_pred * dX. */
+/* Kernel-layout copies of many convolution weights in ONE launch (training: after every optimiser step).
+ * d_items: DEVICE array of n_items descriptors; src = TF-layout kernel [k, cin, cout] float32 (tf.layers.conv1d /
+ * dense with k = 1: /root/reference/modules.py:104-140), dst float32:
+ *   mode 0: [cout, k*cin]  = the transposed operand vc_conv_gemm's groups take (vc_gemm_group.d_Bt),
+ *   mode 1: [cin, k*cout] with the taps reversed = the operand of the data-gradient convolution (decoder.py:236-246's
+ *           tf.gradients through conv1d). */
+typedef struct vc_layout_item {
+    const float* src;
+    float* dst;
+    int32_t k, cin, cout, mode;
+} vc_layout_item;
+int vc_weight_layouts(const vc_layout_item* d_items, int32_t n_items, void* stream);
 int vc_axpby(const float* d_X, int32_t ldx, float a, const float* d_Y, int32_t ldy, float b, float* d_out, int32_t ldo,
              int32_t M, int32_t C, void* stream);
 /* loss = weight * mean((y - t)^2) (decoder.py:187-189); optional d_dY = 2*weight/n * (y - t).

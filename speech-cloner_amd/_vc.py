@@ -76,6 +76,12 @@ class CbhgFrontDesc(C.Structure):
                 ('d_xproj', C.c_void_p), ('ldp', C.c_int32)]
 
 
+class LayoutItem(C.Structure):
+    """struct vc_layout_item (include/vc_hip.h)."""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('k', C.c_int32), ('cin', C.c_int32), ('cout', C.c_int32),
+                ('mode', C.c_int32)]
+
+
 class WgradGroup(C.Structure):
     """struct vc_wgrad_group (include/vc_hip.h)."""
     _fields_ = [('d_dYT', C.c_void_p), ('d_dW', C.c_void_p), ('N', C.c_int32), ('taps', C.c_int32),
@@ -134,6 +140,7 @@ _SIGS = {
     'vc_highway_backward': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     'vc_col_sum': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
     'vc_fill': (C.c_int, [_P, C.c_float, C.c_size_t, _P]),
+    'vc_weight_layouts': (C.c_int, [_P, C.c_int32, _P]),
     'vc_axpby': (C.c_int, [_P, C.c_int32, C.c_float, _P, C.c_int32, C.c_float, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     'vc_mse_loss': (C.c_int, [_P, _P, C.c_size_t, C.c_float, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     'vc_softmax_ce': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),

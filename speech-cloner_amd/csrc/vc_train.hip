@@ -778,6 +778,48 @@ inline int nblocks(size_t n) {
     return (int)(b < 8192 ? (b ? b : 1) : 8192);
 }
 
+// Kernel-layout copies of MANY convolution weights in one launch (the training step rebuilds them after every Adam
+// update: as torch transposes / flips that was ~200 five-microsecond launches per step).  Item i: TF kernel
+// src [k, cin, cout] -> mode 0: dst [cout, k*cin]  (the forward operand of vc_conv_gemm: K contiguous),
+//                       mode 1: dst [cin, k*cout] with the taps reversed (the data-gradient convolution's operand).
+// grid (item, tile runner); 32 x 32 tiles through LDS for mode 0, straight coalesced rows for mode 1.
+__global__ void __launch_bounds__(256)
+weight_layout_kernel(const vc_layout_item* items) {
+    const vc_layout_item it = items[blockIdx.x];
+    const float* src = it.src;
+    float* dst = it.dst;
+    const int k = it.k, cin = it.cin, cout = it.cout;
+    if (it.mode == 0) {
+        __shared__ float tile[32][33];
+        const int rows = k * cin, cols = cout;                      // src [rows, cols] -> dst [cols, rows]
+        const int tr = (rows + 31) / 32, tc = (cols + 31) / 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 x 8
+        for (int t = blockIdx.y; t < tr * tc; t += gridDim.y) {
+            const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = r0 + ty + 8 * i, c = c0 + tx;
+                tile[ty + 8 * i][tx] = (r < rows && c < cols) ? src[(size_t)r * cols + c] : 0.0f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = c0 + ty + 8 * i, r = r0 + tx;
+                if (c < cols && r < rows) dst[(size_t)c * rows + r] = tile[tx][ty + 8 * i];
+            }
+            __syncthreads();
+        }
+    } else {
+        const size_t n = (size_t)k * cin * cout;
+        for (size_t idx = (size_t)blockIdx.y * 256 + threadIdx.x; idx < n; idx += (size_t)gridDim.y * 256) {
+            const int co = (int)(idx % cout);
+            const size_t rest = idx / cout;
+            const int jj = (int)(rest % k), ci = (int)(rest / k);   // dst[ci][jj][co]
+            dst[idx] = src[((size_t)(k - 1 - jj) * cin + ci) * cout + co];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -873,6 +915,13 @@ int vc_col_sum(const float* d_X, int32_t M, int32_t C, int32_t ld, float* d_out,
 int vc_fill(float* d_p, float value, size_t n, void* stream) {
     VC_REQUIRE(d_p, "NULL argument");
     if (n) hipLaunchKernelGGL(fill_kernel, dim3(nblocks(n)), dim3(TB), 0, static_cast<hipStream_t>(stream), d_p, value, n);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_weight_layouts(const vc_layout_item* d_items, int32_t n_items, void* stream) {
+    VC_REQUIRE(d_items && n_items > 0 && n_items <= 65535, "vc_weight_layouts: bad argument");
+    hipLaunchKernelGGL(weight_layout_kernel, dim3((unsigned)n_items, 16), dim3(256), 0, static_cast<hipStream_t>(stream), d_items);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }

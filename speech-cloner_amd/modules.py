@@ -134,6 +134,7 @@ class VariableStore:
 
     def invalidate(self):
         self._cache.clear()
+        self.version = getattr(self, 'version', 0) + 1      # anything derived from the weights outside this cache checks it
 
     def cached(self, key, fn):
         """Kernel-layout copy of weights, built on first use.  The build runs on the CURRENT stream, later

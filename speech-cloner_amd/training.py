@@ -285,9 +285,14 @@ class StageTrainer:
                     R=R, ldr=(R.shape[1] if R is not None else 0), out_f32=True)
         return out
 
-    @staticmethod
-    def _dgrad_conv_weight(W_tf):
-        """[k, Cin, Cout] -> transposed operand of the data-gradient conv: [Cin, k*Cout], taps flipped."""
+    def _dgrad_conv_weight(self, W_tf):
+        """[k, Cin, Cout] -> transposed operand of the data-gradient conv: [Cin, k*Cout], taps flipped.  From the second
+        step on this is the copy _refresh_conv_layouts wrote after the last update (valid while nothing else changed
+        the weights: store.version)."""
+        if getattr(self, '_layout_version', -1) == self.store.version:
+            dg = self._dgrad_w.get(W_tf.data_ptr())
+            if dg is not None:
+                return dg
         k, cin, cout = W_tf.shape
         return W_tf.flip(0).permute(1, 0, 2).reshape(cin, k * cout).contiguous()
 
@@ -367,8 +372,15 @@ class StageTrainer:
                 n = min(32, H - 32 * q)
                 grp.append((64 * q, n, 1, 0, g1[:, 32 * q:], H))
                 grp.append((64 * q + 32, n, 1, 0, g2[:, 32 * q:], H))
-                b1[32 * q:32 * q + n].copy_(dbp[64 * q:64 * q + n])
-                b2[32 * q:32 * q + n].copy_(dbp[64 * q + 32:64 * q + 32 + n])
+            if H % 32 == 0:            # paired order [32 x dense1 | 32 x dense2] per 32 units -> the two bias vectors: two strided copies
+                pr = dbp.view(H // 32, 2, 32)
+                b1.view(H // 32, 32).copy_(pr[:, 0])
+                b2.view(H // 32, 32).copy_(pr[:, 1])
+            else:
+                for q in range((H + 31) // 32):
+                    n = min(32, H - 32 * q)
+                    b1[32 * q:32 * q + n].copy_(dbp[64 * q:64 * q + n])
+                    b2[32 * q:32 * q + n].copy_(dbp[64 * q + 32:64 * q + 32 + n])
             for j in range(0, len(grp), 32):
                 _Ops.wgrad(XT, ldx, H, M, T_, dpT, ldp, grp[j:j + 32])
             # dX = dp @ bt (paired) + direct path
@@ -491,9 +503,41 @@ class StageTrainer:
         lr_t = lr * math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t)
         _vc.check(_lib().vc_adam_step(_p(self.flat), _p(self.grad), _p(self.m), _p(self.v), self.total, lr_t, b1, b2, eps,
                                       1.0 / world, _st()))
-        self.store.invalidate()                   # kernel-layout copies are stale now
+        if getattr(self, '_layout_tab', None) is None:
+            self._conv_seen = {k_: v_ for k_, v_ in self.store._cache.items() if isinstance(k_, tuple) and k_[0] == 'conv'}
+        self.store.invalidate()                   # kernel-layout copies are stale now ...
+        self._refresh_conv_layouts()              # ... except the convolutions', rewritten in place by one launch
         self.dec.opt_state[self.opt_scope + '/global_step'] = np.int32(t)
         return t
+
+    def _refresh_conv_layouts(self):
+        """The forward ([cout, k*cin]) and data-gradient ([cin, k*cout], taps reversed) copies of every convolution
+        kernel, rewritten from the updated weights by ONE launch (vc_weight_layouts) instead of ~200 torch transposes
+        and flips per step.  The table is built after the first step from what the forward pass cached."""
+        torch = _torch()
+        if getattr(self, '_layout_tab', None) is None:
+            items, keep, dgrad = [], {}, {}
+            for key, bt in self._conv_seen.items():
+                W = self.store.vars.get(key[1] + '/conv1d/kernel')
+                if W is None or W.dim() != 3 or bt.dtype != torch.float32:
+                    continue
+                k, cin, cout = W.shape
+                if tuple(bt.shape) != (cout, k * cin) or not bt.is_contiguous():
+                    continue
+                dg = torch.empty((cin, k * cout), dtype=torch.float32, device=W.device)
+                keep[key] = bt
+                dgrad[W.data_ptr()] = dg
+                items.append(_vc.LayoutItem(W.data_ptr(), bt.data_ptr(), k, cin, cout, 0))
+                items.append(_vc.LayoutItem(W.data_ptr(), dg.data_ptr(), k, cin, cout, 1))
+            if not items:
+                return
+            arr = (_vc.LayoutItem * len(items))(*items)
+            tab = torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(self.store.device)
+            self._layout_tab, self._conv_keep, self._dgrad_w = (tab, len(items)), keep, dgrad
+        tab, n = self._layout_tab
+        _vc.check(_lib().vc_weight_layouts(_p(tab), n, _st()))
+        self.store._cache.update(self._conv_keep)
+        self._layout_version = self.store.version
 
 
 class DecoderTrainer(StageTrainer):
