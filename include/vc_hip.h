@@ -290,10 +290,12 @@ typedef struct vc_wgrad_desc {
 int vc_conv_wgrad(const vc_wgrad_desc* desc, void* stream);
 
 /* XT[c, pad + m] = pro(X)[m + row_shift, c] (zero when the shifted frame leaves the window);
- * pro = optional per-channel affine, relu, time max-pool (the forward operand prologue). */
+ * pro = optional per-channel affine, relu, time max-pool (the forward operand prologue).
+ * The launch also writes the zero margins XT[c, 0 .. pad) and XT[c, pad + M .. ldt) of every row c < C and, with
+ * slack_row != 0, a zero row C (d_XT then holds (C + 1) x ldt floats): the buffer need not be initialised. */
 int vc_transpose_pad(const float* d_X, int32_t M, int32_t C, int32_t ld, int32_t T, const float* d_scale,
                      const float* d_shift, int32_t relu, int32_t pool, int32_t row_shift, float* d_XT,
-                     int32_t ldt, int32_t pad, void* stream);
+                     int32_t ldt, int32_t pad, int32_t slack_row, void* stream);
 
 /* Train-mode FusedBatchNorm bookkeeping (modules.py:77-84, is_training): batch mean / biased
  * variance of X [M, C] -> scale/shift (consumed by the next launch's prologue or vc_affine_act),

@@ -129,7 +129,7 @@ _SIGS = {
     'vc_convert': (C.c_int, [_P, C.c_int32, _P, C.c_int32, C.c_size_t, _P]),
     'vc_conv_wgrad': (C.c_int, [C.POINTER(WgradDesc), _P]),
     'vc_transpose_pad': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32,
-                                   C.c_int32, _P, C.c_int32, C.c_int32, _P]),
+                                   C.c_int32, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     'vc_stats_workspace_floats': (C.c_size_t, [C.c_int32, C.c_int32]),
     'vc_bn_train_stats': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_float, C.c_float,
                                     _P, _P, _P, _P, _P, _P]),

@@ -217,7 +217,7 @@ axpby_kernel(const float* X, int ldx, float a, const float* Y, int ldy, float b,
 //   -- the latter builds h_{t-1} / h_{t+1} for the recurrent weight gradients.
 __global__ void __launch_bounds__(TB)
 transpose_pad_kernel(const float* X, int M, int C, int ld, int T, const float* scale, const float* shiftv, int relu,
-                     int pool, int row_shift, float* XT, int ldt, int pad) {
+                     int pool, int row_shift, float* XT, int ldt, int pad, int slack_row) {
     __shared__ float tile[32][33];
     const int m0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
@@ -245,6 +245,25 @@ transpose_pad_kernel(const float* X, int M, int C, int ld, int T, const float* s
     for (int k = ty; k < 32; k += 8) {
         const int c = c0 + k, m = m0 + tx;
         if (c < C && m < M) XT[(size_t)c * ldt + pad + m] = tile[tx][k];
+    }
+    // the zero margins on both sides of every row and the slack row C (the weight-gradient tiles read them): written
+    // here, so the caller hands over an uninitialised buffer instead of zero-filling all (C + 1) x ldt floats first
+    const int tid = threadIdx.x;
+    if (blockIdx.x == 0)
+        for (int i = tid; i < 32 * pad; i += TB) {
+            const int c = c0 + i / pad;
+            if (c < C) XT[(size_t)c * ldt + i % pad] = 0.0f;
+        }
+    if (blockIdx.x == gridDim.x - 1) {
+        const int wr = ldt - (pad + M);
+        for (int i = tid; i < 32 * wr; i += TB) {
+            const int c = c0 + i / wr;
+            if (c < C) XT[(size_t)c * ldt + pad + M + i % wr] = 0.0f;
+        }
+    }
+    if (blockIdx.y == gridDim.y - 1 && slack_row) {
+        const int lo = blockIdx.x == 0 ? 0 : pad + m0, hi = blockIdx.x == gridDim.x - 1 ? ldt : pad + m0 + 32;
+        for (int col = lo + tid; col < hi; col += TB) XT[(size_t)C * ldt + col] = 0.0f;
     }
 }
 
@@ -891,12 +910,12 @@ int vc_highway_backward(const float* d_pre, int32_t NP, const float* d_X, const 
 
 int vc_transpose_pad(const float* d_X, int32_t M, int32_t C, int32_t ld, int32_t T, const float* d_scale,
                      const float* d_shift, int32_t relu, int32_t pool, int32_t row_shift, float* d_XT, int32_t ldt,
-                     int32_t pad, void* stream) {
+                     int32_t pad, int32_t slack_row, void* stream) {
     VC_REQUIRE(d_X && d_XT, "NULL argument");
     VC_REQUIRE(M > 0 && C > 0 && ld >= C && T > 0 && ldt >= M + 2 * pad && pad >= 0, "bad shape");
     VC_REQUIRE(!(d_scale == nullptr) == !(d_shift == nullptr), "scale and shift go together");
     hipLaunchKernelGGL(transpose_pad_kernel, dim3((M + 31) / 32, (C + 31) / 32), dim3(TB), 0, static_cast<hipStream_t>(stream),
-                       d_X, M, C, ld, T, d_scale, d_shift, relu, pool, row_shift, d_XT, ldt, pad);
+                       d_X, M, C, ld, T, d_scale, d_shift, relu, pool, row_shift, d_XT, ldt, pad, slack_row);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }

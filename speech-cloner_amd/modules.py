@@ -312,6 +312,10 @@ def _prep_highway(store, scope, H):
     def build():
         torch = _torch()
         nb = (H + 31) // 32
+        if H % 32 == 0:       # (the training step rebuilds this after every update: three launches, not 4 per 32 units)
+            bt = torch.stack([k1.t().reshape(nb, 32, H), k2.t().reshape(nb, 32, H)], dim=1).reshape(64 * nb, H)
+            bias = torch.stack([b1.view(nb, 32), b2.view(nb, 32)], dim=1).reshape(64 * nb)
+            return bt.to(store.dtype).contiguous(), bias
         bt = torch.zeros((64 * nb, H), dtype=torch.float32, device=store.device)
         bias = torch.zeros((64 * nb,), dtype=torch.float32, device=store.device)
         for q in range(nb):

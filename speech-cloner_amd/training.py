@@ -51,12 +51,13 @@ class _Ops:
 
     @staticmethod
     def transpose(X, M, Cn, ld, T, scale=None, shift=None, relu=0, pool=0, row_shift=0):
-        """-> (buffer [Cn, M + 2*MARGIN] zero-initialised, ldt).  Data starts at column MARGIN."""
+        """-> (buffer [Cn + 1, M + 2*MARGIN], ldt).  Data starts at column MARGIN; the launch itself zeroes the margins
+        and the slack row."""
         torch = _torch()
         ldt = M + 2 * MARGIN
-        buf = torch.zeros((Cn + 1, ldt), dtype=torch.float32, device=X.device)    # + one slack row
+        buf = torch.empty((Cn + 1, ldt), dtype=torch.float32, device=X.device)    # + one slack row
         _vc.check(_lib().vc_transpose_pad(_p(X), M, Cn, ld, T, _p(scale), _p(shift), int(relu), int(pool),
-                                          int(row_shift), _p(buf), ldt, MARGIN, _st()))
+                                          int(row_shift), _p(buf), ldt, MARGIN, 1, _st()))
         return buf, ldt
 
     @staticmethod
