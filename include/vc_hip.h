@@ -219,6 +219,16 @@ typedef struct vc_gemm_desc {
      * element index m*ldc + column; see drop_keep_elem in csrc/vc_gemm.hip). */
     float drop_keep;
     unsigned long long drop_seed;
+    int32_t sum_groups;            /* != 0: the groups are PARTIAL SUMS of one output [M, N] (columns [0, N) of C) instead of
+                                    * column blocks of it: group g convolves input channels [c_off, c_off + Cin) of X with its
+                                    * own taps / pad_l / Bt, and all of them accumulate in the same tile before the epilogue
+                                    * (+ residual) runs once.  This is the data gradient of conv1d_banks (the sum over the banks
+                                    * of dZ_k * W_k^T, tf.gradients through modules.py:144-166) as ONE launch with the banks'
+                                    * whole K.  1: one block per output tile runs every group, then the usual epilogue.
+                                    * S > 1 (<= 16): the groups are dealt to S blocks per tile (g with its mirror n-1-g) and
+                                    * each ADDS its bare float32 partial tile to C with atomics -- C must hold the starting
+                                    * value (zeros or the residual term), no epilogue terms; for launches whose tile count
+                                    * alone would leave the chip idle (summation order then varies from run to run). */
     int32_t epi_pool;              /* 1: store max(y[t], y[t+1]) inside each window of T frames (the last frame keeps
                                     * its value) = tf.layers.max_pooling1d(2, 1, 'same') of the result, fused into the
                                     * producer (modules.py:331 after :329).  Needs act = ReLU and a launch for which

@@ -58,7 +58,7 @@ class GemmDesc(C.Structure):
                 ('d_epi_scale', C.c_void_p), ('d_epi_shift', C.c_void_p), ('act', C.c_int32),
                 ('d_R', C.c_void_p), ('ldr', C.c_int32), ('d_C', C.c_void_p), ('ldc', C.c_int32),
                 ('out_f32', C.c_int32), ('drop_keep', C.c_float), ('drop_seed', C.c_ulonglong),
-                ('epi_pool', C.c_int32)]
+                ('sum_groups', C.c_int32), ('epi_pool', C.c_int32)]
 
 
 CBHG_FRONT_MAX_HIGHWAY = 4

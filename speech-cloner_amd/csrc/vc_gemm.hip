@@ -63,6 +63,7 @@ struct KArgs {
     int32_t ldc, out_f32;
     float drop_keep;               // 0 = no dropout, else keep probability (tf.layers.dropout, training)
     unsigned long long drop_seed;
+    int32_t sum_groups;            // != 0: the groups are partial sums of ONE output; group g reads input channels [c_off, c_off + Cin)
     KGroup g[VC_GEMM_MAX_GROUPS];
 };
 
@@ -445,14 +446,31 @@ conv_kernel(KArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int wm = wid >> 1, wn = wid & 1;
-    const KGroup grp = a.g[a.n_groups - 1 - (int)blockIdx.y];
     const int ntn = (a.N + BN - 1) / BN;
     const int mt = blockIdx.x / ntn, nt = blockIdx.x - mt * ntn;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int K = grp.K, Cin = a.Cin, Tn = a.T, taps = grp.taps, pad_l = grp.pad_l, ldx = a.ldx;
+    const int Cin = a.Cin, Tn = a.T, ldx = a.ldx;
     const int ncs = Cin / BK;
+    const int li = lane & 31, lh = lane >> 5;
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
+    // One group per block (blockIdx.y, heaviest first) -- or, sum_groups: every group in turn into the SAME accumulators
+    // (the data gradient of a filter bank: one launch with the banks' whole K instead of one short-K launch per bank)
+    // With sum_groups = S > 1 the groups are dealt to S blocks per tile (blockIdx.y; group g and its mirror n-1-g go
+    // together, so equal work when the taps grow linearly) and the S partial tiles are added to C with float atomics:
+    // a tile's worth of blocks alone (M/128 x N/128) would leave most of the chip idle.
+    const int g_lo = a.sum_groups ? 0 : a.n_groups - 1 - (int)blockIdx.y, g_hi = a.sum_groups ? a.n_groups : g_lo + 1;
+    for (int gi = g_lo; gi < g_hi; ++gi) {
+    if (a.sum_groups > 1 && min(gi, a.n_groups - 1 - gi) % a.sum_groups != (int)blockIdx.y) continue;
+    const KGroup grp = a.g[gi];
+    const int K = grp.K, taps = grp.taps, pad_l = grp.pad_l;
     const int NR = BM + taps - 1;                         // rows of the resident A tile
-    const T* X = reinterpret_cast<const T*>(a.X);
+    const T* X = reinterpret_cast<const T*>(a.X) + (a.sum_groups ? grp.c_off : 0);
     const T* Bt = reinterpret_cast<const T*>(grp.Bt);
     const bool pool = PRO >= 1 && a.pro_pool != 0;
     const bool nonneg = a.pro_pool == 2 || a.pro_relu;
@@ -480,7 +498,6 @@ conv_kernel(KArgs a) {
         b_row[p] = Bt + (size_t)min(n, a.N - 1) * K + sc * VEC;
     }
     // ---- MFMA roles: lane i of wave (wm, wn) owns output rows wm*64 + mi*32 + i
-    const int li = lane & 31, lh = lane >> 5;
     int jlo[MI], jhi[MI];
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
@@ -536,16 +553,7 @@ conv_kernel(KArgs a) {
         }
     };
 
-    f32x16 acc[MI][2];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.0f;
-
     const int nit = ncs * taps;
-    const EpiCoef coef = epilogue_coef(a, grp, n0, wn, lane);
     gloadA(0);
     gloadB(rbE);                                         // slab 0
     if (nit > 1) gloadB(rbO);                            // slab 1
@@ -610,9 +618,28 @@ conv_kernel(KArgs a) {
         body(it, rbE, rbO);
         if (it + 1 < nit) body(it + 1, rbO, rbE);
     }
+    }   // groups (every K loop ends behind a barrier: the next group's first tiles may overwrite the buffers)
 
     // ---------------------------------------------------------------------------- epilogue
-    epilogue_tile<T, MI>(a, grp, smem, acc, coef, m0, n0, wm * 64, wn, lane, tid);
+    KGroup og = a.g[g_lo];
+    if (a.sum_groups) og.c_off = 0;
+    if (a.sum_groups > 1) {                               // partial tile: C[m, n] += acc (float32 output, no epilogue terms)
+        float* C = reinterpret_cast<float*>(a.C);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int gn = n0 + wn * 64 + ni * 32 + li;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = m0 + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (gm < a.M && gn < a.N) unsafeAtomicAdd(C + (size_t)gm * a.ldc + gn, acc[mi][ni][r]);
+                }
+            }
+        return;
+    }
+    const EpiCoef coef = epilogue_coef(a, og, n0, wn, lane);
+    epilogue_tile<T, MI>(a, og, smem, acc, coef, m0, n0, wm * 64, wn, lane, tid);
 }
 
 template <typename T, int PRO> int launch_conv(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
@@ -623,7 +650,7 @@ template <typename T, int PRO> int launch_conv(const vc_gemm_desc* d, const KArg
                                          hipFuncAttributeMaxDynamicSharedMemorySize, conv_lds_bytes()));
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_kernel<T, PRO>), dim3(ntm * ntn, d->n_groups), dim3(GEMM_THREADS), conv_lds_bytes(), st, ka);
+    hipLaunchKernelGGL((conv_kernel<T, PRO>), dim3(ntm * ntn, d->sum_groups ? d->sum_groups : d->n_groups), dim3(GEMM_THREADS), conv_lds_bytes(), st, ka);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }
@@ -903,6 +930,19 @@ int launch_conv256(const vc_gemm_desc* d, hipStream_t st) {
 }
 
 template <typename T> int launch(const vc_gemm_desc* d, const KArgs& ka, hipStream_t st) {
+    if (d->sum_groups) {             // partial sums over the groups: conv_kernel's group loop is the only form
+        bool ok = d->mode == VC_GEMM_PLAIN && d->Cin % Tr<T>::BK == 0 && d->M >= 128 && !d->epi_pool;
+        for (int g = 0; g < d->n_groups; ++g) ok = ok && d->groups[g].taps <= CONV_MAX_TAPS;
+        if (!ok) return vc::set_error(VC_ERR_INVALID, "vc_conv_gemm: sum_groups needs plain mode, Cin %% %d == 0, M >= 128, taps <= %d",
+                                      Tr<T>::BK, CONV_MAX_TAPS);
+        if (d->sum_groups > 1)
+            VC_REQUIRE((d->out_f32 || sizeof(T) == 4) && !d->d_R && !d->d_epi_scale && !d->d_epi_shift && d->act == VC_ACT_NONE &&
+                           d->drop_keep == 0.0f && d->sum_groups <= 16 && 2 * d->sum_groups <= d->n_groups + 1,
+                       "vc_conv_gemm: sum_groups > 1 adds bare float32 partial tiles to C (no residual / scale / shift / activation), at most (n_groups + 1) / 2 splits");
+        if (d->d_pro_scale || d->pro_relu) return launch_conv<T, 2>(d, ka, st);
+        if (d->pro_pool) return launch_conv<T, 1>(d, ka, st);
+        return launch_conv<T, 0>(d, ka, st);
+    }
     if (sizeof(T) == 2 && proj256_ok(d)) return launch_proj256(d, st);
     if (sizeof(T) == 2 && conv256_ok(d)) return launch_conv256(d, st);
     // convolution-specialised kernel: every group has taps in [2, 32] (a grouped bank launch may
@@ -948,14 +988,18 @@ extern "C" int vc_conv_gemm(const vc_gemm_desc* d, void* stream) {
     ka.pro_scale = d->d_pro_scale; ka.pro_shift = d->d_pro_shift; ka.pro_relu = d->pro_relu; ka.pro_pool = d->pro_pool;
     ka.epi_scale = d->d_epi_scale; ka.epi_shift = d->d_epi_shift; ka.act = d->act;
     ka.R = d->d_R; ka.ldr = d->ldr; ka.C = d->d_C; ka.ldc = d->ldc; ka.out_f32 = d->out_f32;
-    ka.drop_keep = d->drop_keep; ka.drop_seed = d->drop_seed;
+    ka.drop_keep = d->drop_keep; ka.drop_seed = d->drop_seed; ka.sum_groups = d->sum_groups;
     VC_REQUIRE(d->drop_keep >= 0.0f && d->drop_keep <= 1.0f, "drop_keep must be in [0, 1]");
     for (int g = 0; g < d->n_groups; ++g) {
         const vc_gemm_group& gg = d->groups[g];
         VC_REQUIRE(gg.d_Bt != nullptr && (reinterpret_cast<uintptr_t>(gg.d_Bt) & 15) == 0, "group %d: Bt NULL or misaligned", g);
         VC_REQUIRE(gg.taps >= 1 && gg.K == gg.taps * d->Cin, "group %d: K (%d) != taps (%d) * Cin (%d)", g, gg.K, gg.taps, d->Cin);
         VC_REQUIRE(gg.pad_l >= 0 && gg.pad_l < gg.taps, "group %d: bad pad_l %d", g, gg.pad_l);
-        VC_REQUIRE(gg.c_off >= 0 && gg.c_off + d->N <= d->ldc || d->mode == VC_GEMM_HIGHWAY, "group %d: columns exceed ldc", g);
+        if (d->sum_groups)
+            VC_REQUIRE(gg.c_off >= 0 && gg.c_off % vec == 0 && gg.c_off + d->Cin <= d->ldx && d->N <= d->ldc,
+                       "group %d (sum_groups): input channels [c_off, c_off + Cin) must lie inside a row of X", g);
+        else
+            VC_REQUIRE(gg.c_off >= 0 && gg.c_off + d->N <= d->ldc || d->mode == VC_GEMM_HIGHWAY, "group %d: columns exceed ldc", g);
         ka.g[g].Bt = gg.d_Bt; ka.g[g].K = gg.K; ka.g[g].taps = gg.taps; ka.g[g].pad_l = gg.pad_l; ka.g[g].c_off = gg.c_off;
     }
     if (d->epi_pool)

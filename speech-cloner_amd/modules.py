@@ -211,7 +211,7 @@ def _as3(x):
 
 def gemm_desc(X, M, T, Cin, ldx, N, groups, Cout, ldc, vc_dtype, mode=_vc.GEMM_PLAIN,
               pro_scale=None, pro_shift=None, pro_relu=0, pro_pool=0,
-              epi_scale=None, epi_shift=None, act=_vc.ACT_NONE, R=None, ldr=0, out_f32=False, epi_pool=0):
+              epi_scale=None, epi_shift=None, act=_vc.ACT_NONE, R=None, ldr=0, out_f32=False, epi_pool=0, sum_groups=False):
     """Fill a vc_gemm_desc.  groups: list of (Bt tensor [N, K], K, taps, pad_l, c_off)."""
     d = _vc.GemmDesc()
     d.dtype, d.mode = vc_dtype, mode
@@ -230,6 +230,7 @@ def gemm_desc(X, M, T, Cin, ldx, N, groups, Cout, ldc, vc_dtype, mode=_vc.GEMM_P
     d.ldr = ldr
     d.d_C, d.ldc, d.out_f32 = Cout.data_ptr(), ldc, int(bool(out_f32))
     d.epi_pool = int(epi_pool)
+    d.sum_groups = int(sum_groups)
     return d
 
 

@@ -45,8 +45,9 @@ class _Ops:
     """Thin wrappers over the training entry points (float32 device tensors)."""
 
     # vc_wgrad_desc.splits_allowed: the frame reduction of a weight gradient may be split over several workgroups that
-    # add their partial sums with atomics (the gradient arena is zeroed at the start of every step).  0 = one
-    # workgroup per tile, fixed summation order (tests compare the two).
+    # add their partial sums with atomics (the gradient arena is zeroed at the start of every step); likewise the banks
+    # of a filter bank's data gradient (vc_gemm_desc.sum_groups > 1).  0 = one workgroup per tile, fixed summation
+    # order (tests compare the two).
     splits_allowed = 1
 
     @staticmethod
@@ -426,13 +427,31 @@ class StageTrainer:
             grp.append((BANK_FILTERS * (k - 1), BANK_FILTERS, k, -((k - 1) // 2), self.g(sub + '/conv1d/kernel'), BANK_FILTERS))
         _Ops.wgrad(D2T, ldd2, H, M, T_, dZbT, ldzb, grp)
         del D2T, dZbT
-        dD2 = dD2_res.clone()
+        # data gradient of the banks: sum over k of conv(dZb[:, bank k], W_k^T flipped) + the residual path -- ONE launch
+        # whose groups accumulate in the same tile (vc_gemm_desc.sum_groups), not K short-K launches chained through dD2
+        grp = []
         for k in range(1, K + 1):
             sub = b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k))
             Wk = self.w(sub + '/conv1d/kernel')                                      # [k, H, 128]
-            Xk = dZb[:, BANK_FILTERS * (k - 1):]                                     # view: ld = CB, Cin = 128
-            gemm_launch(Xk, M, T_, BANK_FILTERS, CB, H, [(self._dgrad_conv_weight(Wk), k * BANK_FILTERS, k, k - 1 - (k - 1) // 2, 0)],
-                        dD2, H, f32, R=dD2, ldr=H, out_f32=True)
+            grp.append((self._dgrad_conv_weight(Wk), k * BANK_FILTERS, k, k - 1 - (k - 1) // 2, BANK_FILTERS * (k - 1)))
+        if M >= 128 and BANK_FILTERS % 32 == 0:
+            # (M/128 x H/128 tiles alone would leave most of the chip idle: the banks are dealt to S blocks per tile
+            # whose partial sums are added to dD2, which starts as the residual path's gradient)
+            tiles = ((M + 127) // 128) * ((H + 127) // 128)
+            S = 1
+            while _Ops.splits_allowed and tiles * S < 2048 and 4 * S <= K + 1 and S < 16:        # several rounds of resident blocks: short tail
+                S *= 2
+            if S > 1:
+                dD2 = dD2_res.clone()
+                gemm_launch(dZb, M, T_, BANK_FILTERS, CB, H, grp, dD2, H, f32, out_f32=True, sum_groups=S)
+            else:
+                dD2 = torch.empty((M, H), dtype=torch.float32, device=dev)
+                gemm_launch(dZb, M, T_, BANK_FILTERS, CB, H, grp, dD2, H, f32, R=dD2_res, ldr=H, out_f32=True, sum_groups=1)
+        else:                                  # shapes below the convolution kernel's tile: one launch per bank, chained
+            dD2 = dD2_res.clone()
+            for k, (wk, Kk, taps, pad, off) in enumerate(grp, 1):
+                gemm_launch(dZb[:, off:], M, T_, BANK_FILTERS, CB, H, [(wk, Kk, taps, pad, 0)], dD2, H, f32, R=dD2, ldr=H,
+                            out_f32=True)
         del dZb
 
         # ---- prenet

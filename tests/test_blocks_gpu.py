@@ -550,3 +550,39 @@ def test_softmax_dual_output_equals_two_launches():
     torch.cuda.synchronize()
     assert torch.equal(p, q) and torch.equal(c, d) and torch.equal(c, c16) and torch.equal(p16, q16)
     assert q16.shape == (3, 77, 64) and float(q16[..., 61:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('N,T,K,H,S', [(4, 400, 8, 256, 1), (4, 400, 8, 256, 4), (3, 97, 5, 128, 2), (32, 400, 32, 128, 16)])
+def test_summed_groups_is_the_banks_data_gradient(N, T, K, H, S):
+    """vc_gemm_desc.sum_groups: group k convolves input channels [128(k-1), 128k) with its own taps and all groups
+    accumulate in ONE output -- the data gradient of conv1d_banks (tf.gradients through modules.py:144-166).  Against a
+    float64 torch restatement (sum over k of conv1d(dZ_k, W_k) with TF SAME padding per window), for one block per tile
+    (S = 1, fixed order, residual in the epilogue) and for the banks dealt to S blocks that add partial tiles with
+    atomics (the residual then is C's starting value)."""
+    import modules
+    rng = np.random.RandomState(K * 1000 + H + S)
+    F = 128
+    M = N * T
+    dZ = torch.from_numpy(rng.standard_normal((N, T, F * K)).astype(np.float32)).cuda()
+    res = torch.from_numpy(rng.standard_normal((M, H)).astype(np.float32)).cuda()
+    groups, ref = [], res.double().cpu().view(N, T, H).clone()
+    for k in range(1, K + 1):
+        w = (rng.standard_normal((H, k * F)) / np.sqrt(k * F)).astype(np.float32)      # operand layout [N = H, taps * Cin]
+        wt = torch.from_numpy(w).cuda()
+        pad_l = k - 1 - (k - 1) // 2
+        groups.append((wt, k * F, k, pad_l, F * (k - 1)))
+        x = dZ[:, :, F * (k - 1):F * k].double().cpu().permute(0, 2, 1)                 # [N, Cin, T]
+        wk = torch.from_numpy(w).double().view(H, k, F).permute(0, 2, 1)                # [H, Cin, taps]
+        xp = torch.nn.functional.pad(x, (pad_l, k - 1 - pad_l))
+        ref += torch.nn.functional.conv1d(xp, wk).permute(0, 2, 1)
+    if S == 1:
+        out = torch.empty((M, H), dtype=torch.float32, device='cuda')
+        modules.gemm_launch(dZ.view(M, F * K), M, T, F, F * K, H, groups, out, H, _vc.VC_F32, R=res, ldr=H, out_f32=True, sum_groups=1)
+    else:
+        out = res.clone()
+        modules.gemm_launch(dZ.view(M, F * K), M, T, F, F * K, H, groups, out, H, _vc.VC_F32, out_f32=True, sum_groups=S)
+    torch.cuda.synchronize()
+    d = (out.double().cpu().view(N, T, H) - ref).abs().max().item()
+    assert d < 2e-5 * max(1.0, ref.abs().max().item()), d
+    with pytest.raises(_vc.VCError):                      # partial tiles carry no epilogue terms
+        modules.gemm_launch(dZ.view(M, F * K), M, T, F, F * K, H, groups, out, H, _vc.VC_F32, R=res, ldr=H, out_f32=True, sum_groups=2)

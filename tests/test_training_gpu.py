@@ -370,6 +370,9 @@ import dist_util
 from test_training_gpu import _cfg, _setup
 rank, world = dist_util.init('gloo')           # 2 ranks share the one GPU of the test box -> gloo moves the CUDA buffers
 torch.cuda.set_device(0)
+import training
+training._Ops.splits_allowed = 0               # fixed summation order in every gradient kernel: this test is about the
+                                               # exchange, and compares gradients computed twice to 1e-6
 cfg = _cfg()
 dec, w, _, _, _ = _setup(cfg)
 rng = np.random.RandomState(100 + rank)
