@@ -12,6 +12,7 @@ All decoder variables are re-homed into ONE flat float32 arena (plus matching gr
 arenas) so that Adam is a single launch and the all-reduce a single call; every weight-gradient
 kernel writes straight into its TF-layout slice of the gradient arena.
 """
+import contextlib
 import ctypes as C
 import math
 
@@ -50,15 +51,45 @@ class _Ops:
     # order (tests compare the two).
     splits_allowed = 1
 
+    # Weight gradients (their transposed operands, the filter-gradient launches, the bias column sums) are needed only
+    # by the optimiser, not by the rest of the backward pass: with a side stream set they run THERE, behind whatever
+    # the main stream had queued when they were issued, and fill the CUs the latency-bound recurrence kernels leave
+    # idle.  StageTrainer sets / joins it; None = everything on the current stream.
+    side_stream = None
+
+    @staticmethod
+    @contextlib.contextmanager
+    def side(*inputs):
+        """Run the body on the side stream (if any), ordered behind the current stream's queue; `inputs` are tensors of
+        the current stream that the body reads or writes (kept alive for the side stream)."""
+        ws = _Ops.side_stream
+        if ws is None:
+            yield
+            return
+        torch = _torch()
+        ws.wait_stream(torch.cuda.current_stream())
+        for t in inputs:
+            if t is not None:
+                t.record_stream(ws)
+        with torch.cuda.stream(ws):
+            yield
+
+    @staticmethod
+    def join():
+        """The current stream waits for everything issued to the side stream so far."""
+        if _Ops.side_stream is not None:
+            _torch().cuda.current_stream().wait_stream(_Ops.side_stream)
+
     @staticmethod
     def transpose(X, M, Cn, ld, T, scale=None, shift=None, relu=0, pool=0, row_shift=0):
         """-> (buffer [Cn + 1, M + 2*MARGIN], ldt).  Data starts at column MARGIN; the launch itself zeroes the margins
         and the slack row."""
         torch = _torch()
         ldt = M + 2 * MARGIN
-        buf = torch.empty((Cn + 1, ldt), dtype=torch.float32, device=X.device)    # + one slack row
-        _vc.check(_lib().vc_transpose_pad(_p(X), M, Cn, ld, T, _p(scale), _p(shift), int(relu), int(pool),
-                                          int(row_shift), _p(buf), ldt, MARGIN, 1, _st()))
+        with _Ops.side(X, scale, shift):
+            buf = torch.empty((Cn + 1, ldt), dtype=torch.float32, device=X.device)    # + one slack row
+            _vc.check(_lib().vc_transpose_pad(_p(X), M, Cn, ld, T, _p(scale), _p(shift), int(relu), int(pool),
+                                              int(row_shift), _p(buf), ldt, MARGIN, 1, _st()))
         return buf, ldt
 
     @staticmethod
@@ -72,7 +103,8 @@ class _Ops:
             g = d.groups[i]
             g.d_dYT = dYT.data_ptr() + (roff * ldyt + MARGIN) * 4
             g.d_dW, g.N, g.taps, g.shift0, g.ldw = dW.data_ptr(), N, taps, shift0, ldw
-        _vc.check(_lib().vc_conv_wgrad(C.byref(d), _st()))
+        with _Ops.side(XT, dYT):
+            _vc.check(_lib().vc_conv_wgrad(C.byref(d), _st()))
 
     @staticmethod
     def bn_stats(X, M, Cn, gamma, beta, mmean, mvar):
@@ -97,8 +129,9 @@ class _Ops:
     @staticmethod
     def col_sum(X, M, Cn, ld, out, accumulate=0):
         torch = _torch()
-        ws = torch.empty(64 * Cn, dtype=torch.float32, device=X.device)
-        _vc.check(_lib().vc_col_sum(_p(X), M, Cn, ld, _p(out), int(accumulate), _p(ws), _st()))
+        with _Ops.side(X, out):
+            ws = torch.empty(64 * Cn, dtype=torch.float32, device=X.device)
+            _vc.check(_lib().vc_col_sum(_p(X), M, Cn, ld, _p(out), int(accumulate), _p(ws), _st()))
 
 
 class StageTrainer:
@@ -140,6 +173,7 @@ class StageTrainer:
         self.seed = int(c.get('dropout_seed', 1234))
         self.keep = 1.0 - float(c['dropout_rate'])
         self.loss_ws = torch.empty(256, dtype=torch.float32, device=dev)
+        self._side = torch.cuda.Stream(device=dev) if torch.cuda.is_available() else None    # weight gradients (_Ops.side)
         self._pending = []                           # gradient buckets already being all-reduced (data parallel)
         self.overlap_allreduce = True                # False: one blocking all-reduce in apply_gradients (tests)
         self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -335,8 +369,9 @@ class StageTrainer:
         for d, dn in enumerate(('fw', 'bw')):
             cell = '{}/bidirectional_rnn/{}/gru_cell'.format(gs, dn)
             gk, ck = self.g(cell + '/gates/kernel'), self.g(cell + '/candidate/kernel')       # [2H,2H], [2H,H]
-            self.g(cell + '/gates/bias').copy_(dbx[d * 3 * H:d * 3 * H + 2 * H])
-            self.g(cell + '/candidate/bias').copy_(dbx[d * 3 * H + 2 * H:(d + 1) * 3 * H])
+            with _Ops.side(dbx):                                   # (dbx was summed on the side stream)
+                self.g(cell + '/gates/bias').copy_(dbx[d * 3 * H:d * 3 * H + 2 * H])
+                self.g(cell + '/candidate/bias').copy_(dbx[d * 3 * H + 2 * H:(d + 1) * 3 * H])
             grp_x.append((d * 3 * H, 2 * H, 1, 0, gk[:H], 2 * H))                              # x rows of gates/kernel
             grp_x.append((d * 3 * H + 2 * H, H, 1, 0, ck[:H], H))                              # x rows of candidate/kernel
         _Ops.wgrad(YT, ldt, H, M, T_, dpT, ldp, grp_x)
@@ -374,15 +409,16 @@ class StageTrainer:
                 n = min(32, H - 32 * q)
                 grp.append((64 * q, n, 1, 0, g1[:, 32 * q:], H))
                 grp.append((64 * q + 32, n, 1, 0, g2[:, 32 * q:], H))
-            if H % 32 == 0:            # paired order [32 x dense1 | 32 x dense2] per 32 units -> the two bias vectors: two strided copies
-                pr = dbp.view(H // 32, 2, 32)
-                b1.view(H // 32, 32).copy_(pr[:, 0])
-                b2.view(H // 32, 32).copy_(pr[:, 1])
-            else:
-                for q in range((H + 31) // 32):
-                    n = min(32, H - 32 * q)
-                    b1[32 * q:32 * q + n].copy_(dbp[64 * q:64 * q + n])
-                    b2[32 * q:32 * q + n].copy_(dbp[64 * q + 32:64 * q + 32 + n])
+            with _Ops.side(dbp):                                   # (dbp was summed on the side stream)
+                if H % 32 == 0:        # paired order [32 x dense1 | 32 x dense2] per 32 units -> the two bias vectors: two strided copies
+                    pr = dbp.view(H // 32, 2, 32)
+                    b1.view(H // 32, 32).copy_(pr[:, 0])
+                    b2.view(H // 32, 32).copy_(pr[:, 1])
+                else:
+                    for q in range((H + 31) // 32):
+                        n = min(32, H - 32 * q)
+                        b1[32 * q:32 * q + n].copy_(dbp[64 * q:64 * q + n])
+                        b2[32 * q:32 * q + n].copy_(dbp[64 * q + 32:64 * q + 32 + n])
             for j in range(0, len(grp), 32):
                 _Ops.wgrad(XT, ldx, H, M, T_, dpT, ldp, grp[j:j + 32])
             # dX = dp @ bt (paired) + direct path
@@ -498,14 +534,16 @@ class StageTrainer:
         if not self.overlap_allreduce or not (torch.distributed.is_available() and torch.distributed.is_initialized()) \
                 or torch.distributed.get_world_size() < 2:
             return
-        self._pending.append((lo, hi, torch.distributed.all_reduce(self.grad[lo:hi], op=torch.distributed.ReduceOp.SUM,
-                                                                    async_op=True)))
+        with _Ops.side():        # behind the main stream's queue AND the weight gradients issued to the side stream so far
+            self._pending.append((lo, hi, torch.distributed.all_reduce(self.grad[lo:hi], op=torch.distributed.ReduceOp.SUM,
+                                                                        async_op=True)))
 
     def apply_gradients(self, world=1):
         """All-reduce (data parallel), Adam, bookkeeping.  decoder.py:236-246 / encoder.py:171-181.  Buckets that
         forward_backward already put on the wire are waited for; whatever they do not cover is summed here."""
         torch = _torch()
         c = self.cfg
+        _Ops.join()                                   # weight gradients still running on the side stream
         if world > 1:
             pending, self._pending = self._pending, []
             covered = sorted((lo, hi) for lo, hi, _ in pending)
@@ -613,15 +651,21 @@ class DecoderTrainer(StageTrainer):
                 lm, ls = (float(v) for v in self.losses.cpu())
                 dY1.mul_(1.0 / lm)
                 dY2.mul_(1.0 / ls)
-            dX2 = self._stage_backward(s2, sv2, dY2, need_dx=True)
-            del sv2
-            # stage 2's gradients (22.5 M of the 33.2 M floats) are final: their all-reduce runs under stage 1's backward
-            self._start_allreduce(*self._slice_of(s2 + '/'))
-            # y_mel feeds step 2 (decoder.py:155; through the blend with weight f_mel_pred when teacher-forced, :152)
-            _vc.check(_lib().vc_axpby(_p(dY1), dY1.shape[1], 1.0, _p(dX2), dX2.shape[1], f_mel, _p(dY1), dY1.shape[1], M,
-                                      dY1.shape[1], _st()))
-            self._stage_backward(s1, sv1, dY1, need_dx=False)
-            self._start_allreduce(*self._slice_of(s1 + '/'))
+            _Ops.side_stream = self._side             # weight gradients leave the critical path (see _Ops.side)
+            try:
+                dX2 = self._stage_backward(s2, sv2, dY2, need_dx=True)
+                del sv2
+                # stage 2's gradients (22.5 M of the 33.2 M floats) are final once its weight gradients have run: their
+                # all-reduce is queued behind those and travels under stage 1's backward
+                self._start_allreduce(*self._slice_of(s2 + '/'))
+                # y_mel feeds step 2 (decoder.py:155; through the blend with weight f_mel_pred when teacher-forced, :152)
+                _vc.check(_lib().vc_axpby(_p(dY1), dY1.shape[1], 1.0, _p(dX2), dX2.shape[1], f_mel, _p(dY1), dY1.shape[1], M,
+                                          dY1.shape[1], _st()))
+                self._stage_backward(s1, sv1, dY1, need_dx=False)
+                self._start_allreduce(*self._slice_of(s1 + '/'))
+                _Ops.join()                           # whoever reads the gradient arena next finds it complete
+            finally:
+                _Ops.side_stream = None
         return self.losses
 
 
@@ -651,5 +695,10 @@ class EncoderTrainer(StageTrainer):
             ws = torch.empty(3 * M, dtype=torch.float32, device=x.device)
             _vc.check(_lib().vc_softmax_ce(_p(y), _p(target), M, n_out, y.shape[1], _p(dY), y.shape[1], _p(out3), _p(ws), _st()))
             if backward:
-                self._stage_backward(enc._scope, sv, dY, need_dx=False)
+                _Ops.side_stream = self._side
+                try:
+                    self._stage_backward(enc._scope, sv, dY, need_dx=False)
+                    _Ops.join()
+                finally:
+                    _Ops.side_stream = None
         return out3
