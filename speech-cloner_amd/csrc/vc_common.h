@@ -39,6 +39,7 @@ enum Option {
     OPT_WGRAD_XCD,        // 0: weight-gradient tiles dealt round-robin instead of group-per-XCD
     OPT_GRU_MFMA,         // 0: VALU recurrence always, 1: MFMA recurrence always (default: from 32 sequences up)
     OPT_PRENET_LDS,       // 0: every wave of prenet_chain streams the weights itself (default: shared through LDS)
+    OPT_GRU_TRAIN_RESIDENT,   // 0: the float32 training recurrences stream all their weights from L2 every step
     OPT_CBHG_FRONT_MI,    // 4: 128-row blocks in cbhg_small_kernel (default 2)
     OPT_ABLATE_BANK256,   // -DVC_ABLATE only: bit mask, see vc_bank256.h
     OPT_ABLATE_BANK256_ONLY,   // -DVC_ABLATE only: launch one pair alone

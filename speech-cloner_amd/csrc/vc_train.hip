@@ -505,6 +505,117 @@ __device__ __forceinline__ void ms_matvec(const float* __restrict__ w, size_t st
 }
 
 
+// ---------------------------------------------------------------------------- GRU (training), weights partly resident
+// One window per workgroup as above, but every thread keeps the first KRG / KRC weights of its slice of a gate /
+// candidate column in registers for all T steps.  The streaming form is bound by what one CU can pull through its
+// L1 (786 KB per step at H = 256 is >= 5 us at 64 B/clk); here H = 128 streams nothing (all 196 KB resident: 96
+// registers per thread) and H = 256 half of it (192 registers per thread).  Thread roles (NT = 512):
+//   gates:     column cg = tid / TG (2H columns), k-slice sg = tid % TG of KG = H / TG rows      (TG = 512 / 2H)
+//   candidate: column cc = tid / TC (H columns),  k-slice sc = tid % TC of KC = H / TC rows      (TC = 512 / H)
+// slices of one column sit in adjacent lanes and are summed with lane shuffles (no barrier, no LDS).
+template <int H, int KRG, int KRC>
+__global__ void __launch_bounds__(512, 1)
+gru_train_fwd_res_kernel(GruTrainArgs a) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int NT = 512, H3 = 3 * H, TG = NT / (2 * H), KG = H / TG, TC = NT / H, KC = H / TC;
+    static_assert(TG >= 1 && TC >= 1 && KRG <= KG && KRC <= KC && KRG % 4 == 0 && KRC % 4 == 0 && (KG - KRG) % 16 == 0 && (KC - KRC) % 16 == 0, "slices");
+    __shared__ __attribute__((aligned(16))) float h[H];
+    __shared__ __attribute__((aligned(16))) float rhs[H];
+    __shared__ float us[H];
+    const int tid = threadIdx.x;
+    const int seq = blockIdx.x, dir = blockIdx.y;
+    const float* W = a.Wh[dir];
+    const size_t MT = (size_t)a.n_seq * a.T;
+    float* gates = a.gates + (size_t)dir * MT * H3;
+    float* rhg = a.rh + (size_t)dir * MT * H;
+    const int cg = tid / TG, sg = tid % TG, cc = tid / TC, sc = tid % TC;
+    const float* wgp = W + (size_t)(sg * KG) * H3 + cg;            // this thread's gate column slice, row stride H3
+    const float* wcp = W + (size_t)(sc * KC) * H3 + 2 * H + cc;    // ... candidate column slice
+    float wg[KRG > 0 ? KRG : 1], wc[KRC > 0 ? KRC : 1];
+#pragma unroll
+    for (int i = 0; i < KRG; ++i) wg[i] = wgp[(size_t)i * H3];
+#pragma unroll
+    for (int i = 0; i < KRC; ++i) wc[i] = wcp[(size_t)i * H3];
+    for (int i = tid; i < H; i += NT) h[i] = 0.0f;
+    __syncthreads();
+    const size_t xrow = 6 * (size_t)H;
+    const float* xbase = a.xproj + (size_t)seq * a.T * xrow + (size_t)dir * H3;
+    int t = dir ? a.T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    for (int step = 0; step < a.T; ++step, t += dt) {
+        const size_t row = (size_t)seq * a.T + t;
+        // ---- r, u
+        float acc = sg == 0 ? xbase[(size_t)t * xrow + cg] : 0.0f;
+        {
+            const float* hv = h + sg * KG;
+#pragma unroll
+            for (int q = 0; q < KRG / 4; ++q) {
+                const f4 v = *reinterpret_cast<const f4*>(hv + 4 * q);
+                acc = fmaf(v[0], wg[4 * q], acc); acc = fmaf(v[1], wg[4 * q + 1], acc);
+                acc = fmaf(v[2], wg[4 * q + 2], acc); acc = fmaf(v[3], wg[4 * q + 3], acc);
+            }
+#pragma unroll 1
+            for (int k = KRG; k < KG; k += 16) {
+                float wv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = wgp[(size_t)(k + u) * H3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f4 v = *reinterpret_cast<const f4*>(hv + k + 4 * q);
+                    acc = fmaf(v[0], wv[4 * q], acc); acc = fmaf(v[1], wv[4 * q + 1], acc);
+                    acc = fmaf(v[2], wv[4 * q + 2], acc); acc = fmaf(v[3], wv[4 * q + 3], acc);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < TG; o <<= 1) acc += __shfl_xor(acc, o, 64);
+        {
+            const float g = sigmoidf_(acc);
+            if (sg == 0) {
+                gates[row * H3 + cg] = g;
+                if (cg < H) { const float v = g * h[cg]; rhs[cg] = v; rhg[row * H + cg] = v; }
+                else us[cg - H] = g;
+            }
+        }
+        __syncthreads();
+        // ---- candidate, update
+        float ac = sc == 0 ? xbase[(size_t)t * xrow + 2 * H + cc] : 0.0f;
+        {
+            const float* rv = rhs + sc * KC;
+#pragma unroll
+            for (int q = 0; q < KRC / 4; ++q) {
+                const f4 v = *reinterpret_cast<const f4*>(rv + 4 * q);
+                ac = fmaf(v[0], wc[4 * q], ac); ac = fmaf(v[1], wc[4 * q + 1], ac);
+                ac = fmaf(v[2], wc[4 * q + 2], ac); ac = fmaf(v[3], wc[4 * q + 3], ac);
+            }
+#pragma unroll 1
+            for (int k = KRC; k < KC; k += 16) {
+                float wv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = wcp[(size_t)(k + u) * H3];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f4 v = *reinterpret_cast<const f4*>(rv + k + 4 * q);
+                    ac = fmaf(v[0], wv[4 * q], ac); ac = fmaf(v[1], wv[4 * q + 1], ac);
+                    ac = fmaf(v[2], wv[4 * q + 2], ac); ac = fmaf(v[3], wv[4 * q + 3], ac);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < TC; o <<= 1) ac += __shfl_xor(ac, o, 64);
+        const float c = tanhf(ac);
+        const float u = us[cc];
+        const float hn = u * h[cc] + (1.0f - u) * c;
+        if (sc == 0) {
+            gates[row * H3 + 2 * H + cc] = c;
+            a.out[row * 2 * H + (size_t)dir * H + cc] = hn;
+        }
+        __syncthreads();                               // every read of h and rhs of this step is done
+        if (sc == 0) h[cc] = hn;
+        __syncthreads();
+    }
+}
+
 static inline int gru_group_size(int n_seq) { return 2 * n_seq <= 256 ? 1 : (n_seq <= 256 ? 2 : 4); }
 
 template <int GS>
@@ -991,7 +1102,10 @@ int vc_gru_train_forward(const float* d_xproj, const float* d_Wh_fw, const float
         const size_t lds = (3 + (size_t)(nt / H)) * gs * H * 4;
         const dim3 grid((n_seq + gs - 1) / gs, 2);
         hipStream_t st = static_cast<hipStream_t>(stream);
-        if (gs == 1) hipLaunchKernelGGL(gru_train_fwd_ms_kernel<1>, grid, dim3(nt), lds, st, a);
+        const bool resident = gs == 1 && vc::opt(vc::OPT_GRU_TRAIN_RESIDENT) != 0;
+        if (resident && H == 256) hipLaunchKernelGGL((gru_train_fwd_res_kernel<256, 128, 64>), grid, dim3(512), 0, st, a);
+        else if (resident && H == 128) hipLaunchKernelGGL((gru_train_fwd_res_kernel<128, 64, 32>), grid, dim3(512), 0, st, a);
+        else if (gs == 1) hipLaunchKernelGGL(gru_train_fwd_ms_kernel<1>, grid, dim3(nt), lds, st, a);
         else if (gs == 2) hipLaunchKernelGGL(gru_train_fwd_ms_kernel<2>, grid, dim3(nt), lds, st, a);
         else hipLaunchKernelGGL(gru_train_fwd_ms_kernel<4>, grid, dim3(nt), lds, st, a);
     } else {
