@@ -1102,7 +1102,7 @@ int vc_gru_train_forward(const float* d_xproj, const float* d_Wh_fw, const float
         const size_t lds = (3 + (size_t)(nt / H)) * gs * H * 4;
         const dim3 grid((n_seq + gs - 1) / gs, 2);
         hipStream_t st = static_cast<hipStream_t>(stream);
-        const bool resident = gs == 1 && vc::opt(vc::OPT_GRU_TRAIN_RESIDENT) != 0;
+        const bool resident = gs == 1 && vc::opt(vc::OPT_GRU_TRAIN_RESIDENT) == 1;       // (off until measured)
         if (resident && H == 256) hipLaunchKernelGGL((gru_train_fwd_res_kernel<256, 128, 64>), grid, dim3(512), 0, st, a);
         else if (resident && H == 128) hipLaunchKernelGGL((gru_train_fwd_res_kernel<128, 64, 32>), grid, dim3(512), 0, st, a);
         else if (gs == 1) hipLaunchKernelGGL(gru_train_fwd_ms_kernel<1>, grid, dim3(nt), lds, st, a);
