@@ -509,7 +509,8 @@ __device__ __forceinline__ void ms_matvec(const float* __restrict__ w, size_t st
 // One window per workgroup as above, but every thread keeps the first KRG / KRC weights of its slice of a gate /
 // candidate column in registers for all T steps.  The streaming form is bound by what one CU can pull through its
 // L1 (786 KB per step at H = 256 is >= 5 us at 64 B/clk); here H = 128 streams nothing (all 196 KB resident: 96
-// registers per thread) and H = 256 half of it (192 registers per thread).  Thread roles (NT = 512):
+// registers per thread).  KRG / KRC below the slice length leave the rest streaming (H = 256 has room for half).
+// Thread roles (NT = 512):
 //   gates:     column cg = tid / TG (2H columns), k-slice sg = tid % TG of KG = H / TG rows      (TG = 512 / 2H)
 //   candidate: column cc = tid / TC (H columns),  k-slice sc = tid % TC of KC = H / TC rows      (TC = 512 / H)
 // slices of one column sit in adjacent lanes and are summed with lane shuffles (no barrier, no LDS).
@@ -832,6 +833,88 @@ gru_bwd_ms_kernel(GruBwdMsArgs aa) {
 }
 
 
+// BPTT with the recurrent weights resident in registers (H = 128: 32 + 64 per thread), one window per workgroup; the
+// same steps as gru_bwd_ms_kernel<1>.  Thread (k = tid / 4, slice = tid % 4) holds rows [32 slice, +32) of candidate
+// column k and rows [64 slice, +64) of gate column k of W^T; the four slices of a k are adjacent lanes (shuffle sum).
+template <int H>
+__global__ void __launch_bounds__(512, 1)
+gru_bwd_res_kernel(GruBwdMsArgs aa) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const GruBwdArgs& a = aa.b;
+    constexpr int NT = 512, H3 = 3 * H, TP = NT / H, N1 = H / TP, N2 = 2 * H / TP;
+    static_assert(TP == 4 && N1 % 4 == 0 && N2 % 4 == 0, "H = 128");
+    __shared__ __attribute__((aligned(16))) float dh[H];
+    __shared__ __attribute__((aligned(16))) float dcp[H];
+    __shared__ __attribute__((aligned(16))) float dgp[2 * H];
+    __shared__ float drh[H];
+    const int tid = threadIdx.x, k = tid / TP, sl = tid % TP;
+    const int seq = blockIdx.x, dir = blockIdx.y;
+    const float* WT = aa.WhT[dir];                  // WT[col][k] = W[k][col]
+    const size_t MT = (size_t)a.n_seq * a.T;
+    const float* gates = a.gates + (size_t)dir * MT * H3;
+    float w1[N1], w2[N2];
+#pragma unroll
+    for (int i = 0; i < N1; ++i) w1[i] = WT[(size_t)(2 * H + sl * N1 + i) * H + k];
+#pragma unroll
+    for (int i = 0; i < N2; ++i) w2[i] = WT[(size_t)(sl * N2 + i) * H + k];
+    for (int i = tid; i < H; i += NT) dh[i] = 0.0f;
+    __syncthreads();
+    int t = dir ? 0 : a.T - 1;
+    const int dtb = dir ? 1 : -1;
+    for (int step = 0; step < a.T; ++step, t += dtb) {
+        const bool first = (step == a.T - 1);
+        const size_t row = (size_t)seq * a.T + t;
+        if (tid < H) {
+            const int j = tid;
+            const float g = dh[j] + a.dout[row * 2 * H + (size_t)dir * H + j];
+            const float u = gates[row * H3 + H + j], c = gates[row * H3 + 2 * H + j];
+            const float hp = first ? 0.0f : a.out[(row + dtb) * 2 * H + (size_t)dir * H + j];
+            dcp[j] = g * (1.0f - u) * (1.0f - c * c);
+            dgp[H + j] = g * (hp - c) * u * (1.0f - u);
+            dh[j] = g * u;
+        }
+        __syncthreads();
+        {   // d(rh)[k] = sum_j W[k][2H + j] dc_pre[j]
+            float acc = 0.0f;
+            const float* v = dcp + sl * N1;
+#pragma unroll
+            for (int q = 0; q < N1 / 4; ++q) {
+                const f4 x = *reinterpret_cast<const f4*>(v + 4 * q);
+                acc = fmaf(x[0], w1[4 * q], acc); acc = fmaf(x[1], w1[4 * q + 1], acc);
+                acc = fmaf(x[2], w1[4 * q + 2], acc); acc = fmaf(x[3], w1[4 * q + 3], acc);
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            if (sl == 0) drh[k] = acc;
+        }
+        __syncthreads();
+        if (tid < H) {
+            const int j = tid;
+            const float r = gates[row * H3 + j];
+            const float hp = first ? 0.0f : a.out[(row + dtb) * 2 * H + (size_t)dir * H + j];
+            dgp[j] = drh[j] * hp * r * (1.0f - r);
+            dh[j] += drh[j] * r;
+        }
+        __syncthreads();
+        {   // dh_prev[k] += sum_{j < 2H} W[k][j] dg_pre[j]
+            float acc = 0.0f;
+            const float* v = dgp + sl * N2;
+#pragma unroll
+            for (int q = 0; q < N2 / 4; ++q) {
+                const f4 x = *reinterpret_cast<const f4*>(v + 4 * q);
+                acc = fmaf(x[0], w2[4 * q], acc); acc = fmaf(x[1], w2[4 * q + 1], acc);
+                acc = fmaf(x[2], w2[4 * q + 2], acc); acc = fmaf(x[3], w2[4 * q + 3], acc);
+            }
+            acc += __shfl_xor(acc, 1, 64);
+            acc += __shfl_xor(acc, 2, 64);
+            if (sl == 0) dh[k] += acc;
+        }
+        if (tid < H3) a.dpre[row * 6 * (size_t)H + (size_t)dir * H3 + tid] = tid < 2 * H ? dgp[tid] : dcp[tid - 2 * H];
+        __syncthreads();
+    }
+}
+
+
 // ---------------------------------------------------------------------------- encoder loss / metrics
 // tf.nn.softmax_cross_entropy_with_logits_v2 + reduce_mean (/root/reference/encoder.py:134-137),
 // accuracy of argmax(pred) vs argmax(target) and mean squared error of the posteriors
@@ -1102,9 +1185,11 @@ int vc_gru_train_forward(const float* d_xproj, const float* d_Wh_fw, const float
         const size_t lds = (3 + (size_t)(nt / H)) * gs * H * 4;
         const dim3 grid((n_seq + gs - 1) / gs, 2);
         hipStream_t st = static_cast<hipStream_t>(stream);
-        const bool resident = gs == 1 && vc::opt(vc::OPT_GRU_TRAIN_RESIDENT) == 1;       // (off until measured)
-        if (resident && H == 256) hipLaunchKernelGGL((gru_train_fwd_res_kernel<256, 128, 64>), grid, dim3(512), 0, st, a);
-        else if (resident && H == 128) hipLaunchKernelGGL((gru_train_fwd_res_kernel<128, 64, 32>), grid, dim3(512), 0, st, a);
+        // H = 128: all 196 KB of weights in registers, 1.38 -> 0.63 ms per launch at 32 windows.  (H = 256 with HALF of them
+        // resident measured no faster than streaming everything -- 3.17 vs 3.14 ms: the step is the latency chain of the
+        // streamed batches, not the bytes -- and is not instantiated.)
+        const bool resident = gs == 1 && H == 128 && vc::opt(vc::OPT_GRU_TRAIN_RESIDENT) != 0;
+        if (resident) hipLaunchKernelGGL((gru_train_fwd_res_kernel<128, 64, 32>), grid, dim3(512), 0, st, a);
         else if (gs == 1) hipLaunchKernelGGL(gru_train_fwd_ms_kernel<1>, grid, dim3(nt), lds, st, a);
         else if (gs == 2) hipLaunchKernelGGL(gru_train_fwd_ms_kernel<2>, grid, dim3(nt), lds, st, a);
         else hipLaunchKernelGGL(gru_train_fwd_ms_kernel<4>, grid, dim3(nt), lds, st, a);
@@ -1131,7 +1216,9 @@ int vc_gru_backward(const float* d_dout, const float* d_out, const float* d_gate
         const size_t lds = (5 + (size_t)(nt >= H ? nt / H : 1)) * gs * H * 4;
         const dim3 grid((n_seq + gs - 1) / gs, 2);
         hipStream_t st = static_cast<hipStream_t>(stream);
-        if (gs == 1) hipLaunchKernelGGL(gru_bwd_ms_kernel<1>, grid, dim3(nt), lds, st, aa);
+        if (gs == 1 && H == 128 && vc::opt(vc::OPT_GRU_TRAIN_RESIDENT) != 0)
+            hipLaunchKernelGGL(gru_bwd_res_kernel<128>, grid, dim3(512), 0, st, aa);
+        else if (gs == 1) hipLaunchKernelGGL(gru_bwd_ms_kernel<1>, grid, dim3(nt), lds, st, aa);
         else if (gs == 2) hipLaunchKernelGGL(gru_bwd_ms_kernel<2>, grid, dim3(nt), lds, st, aa);
         else hipLaunchKernelGGL(gru_bwd_ms_kernel<4>, grid, dim3(nt), lds, st, aa);
     } else
