@@ -475,6 +475,9 @@ gru_bwd_kernel(GruBwdArgs a) {
 // acc[s] += sum_k vec[s][k] * w[k * stride]  for k in [0, n): the weight column is read in batches
 // of 16 independent loads (a 4-load batch per iteration left each wave waiting on L2 64-128 times
 // per phase and step: the recurrences were latency-bound).  n must be a multiple of 4.
+#ifdef VC_ABLATE
+__device__ int g_gru_train_ablate;                  // -DVC_ABLATE builds only: set by vc_ablate_set_gru_train
+#endif
 template <int S>
 __device__ __forceinline__ void ms_matvec(const float* __restrict__ w, size_t stride, const float* vec, int vstride, int n,
                                           float (&acc)[S]) {
@@ -482,6 +485,12 @@ __device__ __forceinline__ void ms_matvec(const float* __restrict__ w, size_t st
     int k = 0;
     for (; k + 16 <= n; k += 16) {
         float wv[16];
+#ifdef VC_ABLATE
+        if (g_gru_train_ablate) {                            // timing only: no weight stream (tools/ab_gru_train.py --floor)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = 0.001f * (float)(k + u);
+        } else
+#endif
 #pragma unroll
         for (int u = 0; u < 16; ++u) wv[u] = w[(size_t)(k + u) * stride];
 #pragma unroll
@@ -505,11 +514,16 @@ __device__ __forceinline__ void ms_matvec(const float* __restrict__ w, size_t st
 }
 
 
+// Workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every outstanding global store; a
+// recurrence step stores its gates / r*h / output rows right before each barrier and never reads them back).  Measured:
+// it makes no difference to the step time -- what did was requesting a step's global operands one step ahead.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------------------- GRU (training), weights partly resident
 // One window per workgroup as above, but every thread keeps the first KRG / KRC weights of its slice of a gate /
 // candidate column in registers for all T steps.  The streaming form is bound by what one CU can pull through its
 // L1 (786 KB per step at H = 256 is >= 5 us at 64 B/clk); here H = 128 streams nothing (all 196 KB resident: 96
-// registers per thread).  KRG / KRC below the slice length leave the rest streaming (H = 256 has room for half).
+// registers per thread); H = 256 keeps half (KRG / KRC below the slice length leave the rest streaming).
 // Thread roles (NT = 512):
 //   gates:     column cg = tid / TG (2H columns), k-slice sg = tid % TG of KG = H / TG rows      (TG = 512 / 2H)
 //   candidate: column cc = tid / TC (H columns),  k-slice sc = tid % TC of KC = H / TC rows      (TC = 512 / H)
@@ -538,15 +552,21 @@ gru_train_fwd_res_kernel(GruTrainArgs a) {
 #pragma unroll
     for (int i = 0; i < KRC; ++i) wc[i] = wcp[(size_t)i * H3];
     for (int i = tid; i < H; i += NT) h[i] = 0.0f;
-    __syncthreads();
+    lds_barrier();
     const size_t xrow = 6 * (size_t)H;
     const float* xbase = a.xproj + (size_t)seq * a.T * xrow + (size_t)dir * H3;
     int t = dir ? a.T - 1 : 0;
     const int dt = dir ? -1 : 1;
+    // the input projections of a step are requested a whole step ahead: their L2 / HBM round trip (two per step) was
+    // most of what was left of a step once the weights had become resident
+    float xg = sg == 0 ? xbase[(size_t)t * xrow + cg] : 0.0f, xc = sc == 0 ? xbase[(size_t)t * xrow + 2 * H + cc] : 0.0f;
     for (int step = 0; step < a.T; ++step, t += dt) {
         const size_t row = (size_t)seq * a.T + t;
+        const int tn = step + 1 < a.T ? t + dt : t;
+        const float xg_n = sg == 0 ? xbase[(size_t)tn * xrow + cg] : 0.0f;
+        const float xc_n = sc == 0 ? xbase[(size_t)tn * xrow + 2 * H + cc] : 0.0f;
         // ---- r, u
-        float acc = sg == 0 ? xbase[(size_t)t * xrow + cg] : 0.0f;
+        float acc = xg;
         {
             const float* hv = h + sg * KG;
 #pragma unroll
@@ -578,9 +598,9 @@ gru_train_fwd_res_kernel(GruTrainArgs a) {
                 else us[cg - H] = g;
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- candidate, update
-        float ac = sc == 0 ? xbase[(size_t)t * xrow + 2 * H + cc] : 0.0f;
+        float ac = xc;
         {
             const float* rv = rhs + sc * KC;
 #pragma unroll
@@ -611,9 +631,11 @@ gru_train_fwd_res_kernel(GruTrainArgs a) {
             gates[row * H3 + 2 * H + cc] = c;
             a.out[row * 2 * H + (size_t)dir * H + cc] = hn;
         }
-        __syncthreads();                               // every read of h and rhs of this step is done
+        lds_barrier();                               // every read of h and rhs of this step is done
         if (sc == 0) h[cc] = hn;
-        __syncthreads();
+        lds_barrier();
+        xg = xg_n;
+        xc = xc_n;
     }
 }
 
@@ -858,22 +880,34 @@ gru_bwd_res_kernel(GruBwdMsArgs aa) {
 #pragma unroll
     for (int i = 0; i < N2; ++i) w2[i] = WT[(size_t)(sl * N2 + i) * H + k];
     for (int i = tid; i < H; i += NT) dh[i] = 0.0f;
-    __syncthreads();
+    lds_barrier();
     int t = dir ? 0 : a.T - 1;
     const int dtb = dir ? 1 : -1;
+    // a step's operands (dout, the saved gates, the previous state) are requested a whole step ahead
+    float p_do = 0.0f, p_r = 0.0f, p_u = 0.0f, p_c = 0.0f, p_hp = 0.0f;
+    auto fetch = [&](int tt, bool is_first) {
+        if (tid < H) {
+            const size_t rw = (size_t)seq * a.T + tt;
+            p_do = a.dout[rw * 2 * H + (size_t)dir * H + tid];
+            p_r = gates[rw * H3 + tid]; p_u = gates[rw * H3 + H + tid]; p_c = gates[rw * H3 + 2 * H + tid];
+            p_hp = is_first ? 0.0f : a.out[(rw + dtb) * 2 * H + (size_t)dir * H + tid];
+        }
+    };
+    fetch(t, a.T == 1);
     for (int step = 0; step < a.T; ++step, t += dtb) {
-        const bool first = (step == a.T - 1);
         const size_t row = (size_t)seq * a.T + t;
+        const float c_do = p_do, c_r = p_r, c_u = p_u, c_c = p_c, c_hp = p_hp;
+        if (step + 1 < a.T) fetch(t + dtb, step + 1 == a.T - 1);
         if (tid < H) {
             const int j = tid;
-            const float g = dh[j] + a.dout[row * 2 * H + (size_t)dir * H + j];
-            const float u = gates[row * H3 + H + j], c = gates[row * H3 + 2 * H + j];
-            const float hp = first ? 0.0f : a.out[(row + dtb) * 2 * H + (size_t)dir * H + j];
+            const float g = dh[j] + c_do;
+            const float u = c_u, c = c_c;
+            const float hp = c_hp;
             dcp[j] = g * (1.0f - u) * (1.0f - c * c);
             dgp[H + j] = g * (hp - c) * u * (1.0f - u);
             dh[j] = g * u;
         }
-        __syncthreads();
+        lds_barrier();
         {   // d(rh)[k] = sum_j W[k][2H + j] dc_pre[j]
             float acc = 0.0f;
             const float* v = dcp + sl * N1;
@@ -887,15 +921,15 @@ gru_bwd_res_kernel(GruBwdMsArgs aa) {
             acc += __shfl_xor(acc, 2, 64);
             if (sl == 0) drh[k] = acc;
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < H) {
             const int j = tid;
-            const float r = gates[row * H3 + j];
-            const float hp = first ? 0.0f : a.out[(row + dtb) * 2 * H + (size_t)dir * H + j];
+            const float r = c_r;
+            const float hp = c_hp;
             dgp[j] = drh[j] * hp * r * (1.0f - r);
             dh[j] += drh[j] * r;
         }
-        __syncthreads();
+        lds_barrier();
         {   // dh_prev[k] += sum_{j < 2H} W[k][j] dg_pre[j]
             float acc = 0.0f;
             const float* v = dgp + sl * N2;
@@ -910,7 +944,7 @@ gru_bwd_res_kernel(GruBwdMsArgs aa) {
             if (sl == 0) dh[k] += acc;
         }
         if (tid < H3) a.dpre[row * 6 * (size_t)H + (size_t)dir * H3 + tid] = tid < 2 * H ? dgp[tid] : dcp[tid - 2 * H];
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -1185,11 +1219,12 @@ int vc_gru_train_forward(const float* d_xproj, const float* d_Wh_fw, const float
         const size_t lds = (3 + (size_t)(nt / H)) * gs * H * 4;
         const dim3 grid((n_seq + gs - 1) / gs, 2);
         hipStream_t st = static_cast<hipStream_t>(stream);
-        // H = 128: all 196 KB of weights in registers, 1.38 -> 0.63 ms per launch at 32 windows.  (H = 256 with HALF of them
-        // resident measured no faster than streaming everything -- 3.17 vs 3.14 ms: the step is the latency chain of the
-        // streamed batches, not the bytes -- and is not instantiated.)
-        const bool resident = gs == 1 && H == 128 && vc::opt(vc::OPT_GRU_TRAIN_RESIDENT) != 0;
-        if (resident) hipLaunchKernelGGL((gru_train_fwd_res_kernel<128, 64, 32>), grid, dim3(512), 0, st, a);
+        // H = 128: all 196 KB of weights in registers and the step's input projections requested a step ahead: 1.38 -> 0.53 ms
+        // per launch at 32 windows.  H = 256: half of the 786 KB resident (192 registers per thread): 3.14 -> 2.95 ms -- the
+        // step there is mostly NOT the weight stream (2.5 ms remain with the loads removed: tools/ab_gru_train.py --floor).
+        const bool resident = gs == 1 && vc::opt(vc::OPT_GRU_TRAIN_RESIDENT) != 0;
+        if (resident && H == 128) hipLaunchKernelGGL((gru_train_fwd_res_kernel<128, 64, 32>), grid, dim3(512), 0, st, a);
+        else if (resident && H == 256) hipLaunchKernelGGL((gru_train_fwd_res_kernel<256, 128, 64>), grid, dim3(512), 0, st, a);
         else if (gs == 1) hipLaunchKernelGGL(gru_train_fwd_ms_kernel<1>, grid, dim3(nt), lds, st, a);
         else if (gs == 2) hipLaunchKernelGGL(gru_train_fwd_ms_kernel<2>, grid, dim3(nt), lds, st, a);
         else hipLaunchKernelGGL(gru_train_fwd_ms_kernel<4>, grid, dim3(nt), lds, st, a);
@@ -1199,6 +1234,13 @@ int vc_gru_train_forward(const float* d_xproj, const float* d_Wh_fw, const float
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }
+
+#ifdef VC_ABLATE
+int vc_ablate_set_gru_train(int32_t v) {
+    VC_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_gru_train_ablate), &v, sizeof(int)));
+    return VC_OK;
+}
+#endif
 
 int vc_gru_backward(const float* d_dout, const float* d_out, const float* d_gates, const float* d_Wh_fw,
                     const float* d_Wh_bw, const float* d_WhT_fw, const float* d_WhT_bw, int32_t n_seq, int32_t T,

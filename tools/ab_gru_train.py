@@ -8,6 +8,10 @@ import torch, _vc, bench
 lib = _vc.lib()
 P = lambda t: C.c_void_p(t.data_ptr())
 torch.manual_seed(0)
+if '--floor' in sys.argv:          # -DVC_ABLATE build: the streaming kernels without their weight stream (timing only)
+    assert lib.vc_ablate_build()
+    fn = lib.vc_ablate_set_gru_train; fn.restype = C.c_int; fn.argtypes = [C.c_int32]
+    assert fn(1) == 0
 for H in (256, 128):
     N, T = 32, 400
     xproj = torch.randn(N * T, 6 * H, device='cuda') * 0.5
