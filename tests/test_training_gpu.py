@@ -480,3 +480,53 @@ def test_encoder_train_step_matches_autograd(golden_dir):
     assert r[3] == 136513 and r[4] is None and np.isfinite(r[0])
     a_, m_, l_ = enc.exec_calc_metrics(x, target)
     assert 0.0 <= a_ <= 1.0 and np.isfinite(l_)
+
+
+def test_weight_layouts_in_one_launch():
+    """vc_weight_layouts: the forward ([cout, k*cin]) and data-gradient ([cin, k*cout], taps reversed) copies of many
+    convolution kernels in one launch are exactly the torch transposes / flips the trainer used to launch one by one
+    (ragged sizes, k = 1 .. 32), and a trainer's second step -- the first that runs on the refreshed copies -- gives the
+    same losses as a trainer that rebuilds every copy with torch."""
+    import ctypes as C
+    import _vc
+    rng = np.random.RandomState(3)
+    shapes = [(1, 61, 256), (3, 4096, 128), (32, 256, 128), (7, 40, 40), (2, 33, 65), (5, 128, 256)]
+    items, checks = [], []
+    for k, cin, cout in shapes:
+        W = torch.from_numpy(rng.standard_normal((k, cin, cout)).astype(np.float32)).cuda()
+        fwd = torch.full((cout, k * cin), float('nan'), device='cuda')
+        dg = torch.full((cin, k * cout), float('nan'), device='cuda')
+        items += [_vc.LayoutItem(W.data_ptr(), fwd.data_ptr(), k, cin, cout, 0), _vc.LayoutItem(W.data_ptr(), dg.data_ptr(), k, cin, cout, 1)]
+        checks.append((W, fwd, dg))
+    arr = (_vc.LayoutItem * len(items))(*items)
+    tab = torch.frombuffer(bytearray(arr), dtype=torch.uint8).cuda()
+    _vc.check(_vc.lib().vc_weight_layouts(C.c_void_p(tab.data_ptr()), len(items), _vc.current_stream()))
+    torch.cuda.synchronize()
+    for W, fwd, dg in checks:
+        k, cin, cout = W.shape
+        assert torch.equal(fwd, W.reshape(k * cin, cout).t().contiguous())
+        assert torch.equal(dg, W.flip(0).permute(1, 0, 2).reshape(cin, k * cout).contiguous())
+    # two steps with and without the in-place refresh
+    import training
+    cfg = _cfg()
+    rng = np.random.RandomState(9)
+    ppg = torch.softmax(torch.from_numpy(rng.standard_normal((4, 40, 61)) * 2), -1).float().cuda()
+    mel = torch.from_numpy(rng.uniform(0, 0.8, (4, 40, 80)).astype(np.float32)).cuda()
+    stft = torch.from_numpy(rng.uniform(0, 0.8, (4, 40, 201)).astype(np.float32)).cuda()
+    out = []
+    training._Ops.splits_allowed = 0            # fixed summation order in the gradient kernels: the two runs must agree exactly
+    try:
+        for refresh in (True, False):
+            dec, _, _, _, _ = _setup(_cfg())
+            tr = dec._get_trainer()
+            if not refresh:
+                tr._refresh_conv_layouts = lambda: None
+            losses = []
+            for _ in range(3):
+                l = tr.forward_backward(ppg, mel, stft).clone()
+                tr.apply_gradients(1)
+                losses.append(l.cpu().numpy())
+            out.append(np.stack(losses))
+    finally:
+        training._Ops.splits_allowed = 1
+    assert np.array_equal(out[0], out[1]), (out[0], out[1])
