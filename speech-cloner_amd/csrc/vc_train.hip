@@ -12,6 +12,9 @@
 namespace {
 
 constexpr int TB = 256;
+// rows summed by one block of the column-statistics kernels: 64 (was 256) gives the 12,800 x 4,096 bank tensors 3,200
+// blocks instead of 800 -- these loops are load-latency bound, more waves hide more of it
+constexpr int BN_ROWS = 64;
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
@@ -1072,7 +1075,7 @@ weight_layout_kernel(const vc_layout_item* items) {
 extern "C" {
 
 size_t vc_stats_workspace_floats(int32_t M, int32_t C) {
-    const int rows = 256;
+    const int rows = BN_ROWS;
     const int nblk = (M + rows - 1) / rows;
     return (size_t)nblk * 2 * C;
 }
@@ -1083,7 +1086,7 @@ int vc_bn_train_stats(const float* d_X, int32_t M, int32_t C, int32_t ld, const 
     VC_REQUIRE(d_X && d_gamma && d_beta && d_scale && d_shift && d_mean && d_rstd && d_workspace, "NULL argument");
     VC_REQUIRE(M > 0 && C > 0 && ld >= C, "bad shape");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int rows = 256, nblk = (M + rows - 1) / rows;
+    const int rows = BN_ROWS, nblk = (M + rows - 1) / rows;
     hipLaunchKernelGGL(col_stats_partial_kernel, dim3((C + TB - 1) / TB, nblk), dim3(TB), 0, st, d_X, M, C, ld, rows, d_workspace);
     hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((C + TB - 1) / TB), dim3(TB), 0, st, d_workspace, nblk, M, C, d_gamma,
                        d_beta, d_moving_mean, d_moving_var, decay, eps, d_scale, d_shift, d_mean, d_rstd);
@@ -1107,7 +1110,7 @@ int vc_bn_backward(const float* d_G, const float* d_X, int32_t M, int32_t C, int
                "NULL argument");
     VC_REQUIRE(M > 0 && C > 0 && ld >= C && T > 0 && M % T == 0 && mode >= 0 && mode <= 2, "bad shape/mode");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const int rows = 256, nblk = (M + rows - 1) / rows;
+    const int rows = BN_ROWS, nblk = (M + rows - 1) / rows;
     hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((C + TB - 1) / TB, nblk), dim3(TB), 0, st, d_G, d_X, M, C, ld, T, d_scale,
                        d_shift, d_mean, d_rstd, mode, rows, d_workspace);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + TB - 1) / TB), dim3(TB), 0, st, d_workspace, nblk, C, d_dbeta, d_dgamma);
