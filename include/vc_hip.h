@@ -55,8 +55,8 @@ const char* vc_target_arch(void);
  *   "gru_mfma"       0 = VALU recurrence always, 1 = MFMA recurrence always (default: from 32 sequences up)
  *   "prenet_lds"     0 = every wave of the fused prenet streams the weights from L2 itself (default: one stream per
  *                    block, shared through LDS)
- *   "gru_train_resident" 0 = the float32 training recurrences of 128 units stream their weights from L2 every step
- *                    (default: all of them in registers)
+ *   "gru_train_resident" 0 = the float32 training recurrences stream all their weights from L2 every step (default:
+ *                    128 units: all of them in registers, forward and backward; 256 units: half, forward)
  *   "cbhg_front_mi"  4 = 128-row blocks in the fused encoder front
  * All alternatives compute the same function (tests compare them).  Three more names, "ablate_bank256",
  * "ablate_bank256_only" and "ablate_cbhg_front", skip parts of a kernel for timing and give WRONG results: they
