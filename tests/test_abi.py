@@ -45,6 +45,37 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(_vc.FrontendCfg) == 14 * 4
 
 
+def test_every_struct_field_sits_where_the_header_puts_it(tmp_path):
+    """The ctypes mirrors of the header's structs, checked against the C compiler: a small program that includes
+    include/vc_hip.h prints sizeof and every field's offsetof; each must equal ctypes' (same field names, same order).
+    A field added on one side only -- or in a different place -- fails here, not as a wrong launch on the GPU."""
+    import os
+    import subprocess
+    import _vc
+    from conftest import ROOT
+    pairs = [('vc_frontend_cfg', _vc.FrontendCfg), ('vc_gemm_group', _vc.GemmGroup), ('vc_gemm_desc', _vc.GemmDesc),
+             ('vc_wgrad_group', _vc.WgradGroup), ('vc_wgrad_desc', _vc.WgradDesc), ('vc_layout_item', _vc.LayoutItem),
+             ('vc_cbhg_front_desc', _vc.CbhgFrontDesc)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vc_hip.h"', 'int main(void) {']
+    for cname, cls in pairs:
+        lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = {}
+    for ln in subprocess.check_output([str(exe)], text=True).splitlines():
+        a, b, c = ln.split()
+        got[(a, b)] = int(c)
+    for cname, cls in pairs:
+        assert got[(cname, 'sizeof')] == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert got[(cname, fname)] == getattr(cls, fname).offset, (cname, fname)
+
+
 def test_fused_launch_shape_queries_and_validation_without_gpu():
     """The shape predicates of the fused launches are pure host code, and argument validation of the fused entry
     points fails (loudly, with a message) before any HIP call."""
