@@ -27,6 +27,44 @@ def test_header_symbols_exported():
     assert set(_vc._SIGS) == set(names), set(_vc._SIGS) ^ set(names)
 
 
+def test_ctypes_signatures_follow_the_header_prototypes():
+    """Argument count and kind (pointer / int32 / size_t / float) of every entry of _vc._SIGS against the prototype in
+    include/vc_hip.h: an argument added, dropped or moved on one side only fails here."""
+    import _vc
+    from conftest import ROOT
+    src = open(os.path.join(ROOT, 'include', 'vc_hip.h')).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    protos = dict((m.group(2), (m.group(1), m.group(3))) for m in
+                  re.finditer(r'\n([A-Za-z_][\w \*]*?)\b(vc_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;', src))
+    assert set(protos) == set(_vc._SIGS)
+
+    def kind_c(decl):
+        d = ' '.join(decl.split())
+        if '*' in d:
+            return 'ptr'
+        if d.startswith('size_t'):
+            return 'size'
+        if d.startswith('float'):
+            return 'float'
+        if d.startswith('int32_t') or d.startswith('int '):
+            return 'int'
+        if d.startswith('int64_t') or d.startswith('unsigned long long') or d.startswith('uint64_t'):
+            return 'i64'
+        raise AssertionError('unhandled C parameter: ' + d)
+
+    def kind_py(t):
+        if t is ctypes.c_void_p or t is ctypes.c_char_p or (isinstance(t, type) and issubclass(t, ctypes._Pointer)):
+            return 'ptr'
+        return {ctypes.c_float: 'float', ctypes.c_int32: 'int', ctypes.c_int64: 'i64', ctypes.c_uint64: 'i64', ctypes.c_size_t: 'size'}[t]
+
+    for name, (ret, args) in protos.items():
+        c_args = [] if args.strip() in ('', 'void') else [a for a in args.split(',')]
+        py_ret, py_args = _vc._SIGS[name]
+        assert len(c_args) == len(py_args), (name, len(c_args), len(py_args))
+        for i, (ca, pa) in enumerate(zip(c_args, py_args)):
+            assert kind_c(ca) == kind_py(pa), (name, i, ca.strip(), pa)
+
+
 def test_version_and_errors_without_gpu():
     import _vc
     lib = _vc.lib()
