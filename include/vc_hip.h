@@ -35,7 +35,10 @@ extern "C" {
 #define VC_ERR_WORKSPACE 3    /* workspace too small */
 #define VC_ERR_UNSUPPORTED 4
 
-#define VC_ABI_VERSION 1
+/* 2: vc_frontend_f32 / vc_frontend_stages_f32 take out_rows, vc_transpose_pad takes slack_row, vc_gemm_desc has
+ *    sum_groups.  Bump on EVERY change of an exported signature or struct layout: the Python binding (_vc.py) refuses
+ *    to load a library whose vc_version() differs from its own constant. */
+#define VC_ABI_VERSION 2
 
 int vc_version(void);
 const char* vc_last_error(void);

@@ -18,6 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VC_LIB_PATH', os.path.join(_HERE, 'libvc_hip.so'))   # override: kernel A/B experiments
 
 VC_OK = 0
+VC_ABI_VERSION = 2      # include/vc_hip.h: VC_ABI_VERSION -- lib() refuses a library that reports another one
 
 
 class VCError(RuntimeError):
@@ -187,6 +188,13 @@ def lib():
         # device" from the second one), so torch is imported before the dlopen.
         import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
+        h.vc_version.restype, h.vc_version.argtypes = C.c_int, []
+        got = h.vc_version()
+        if got != VC_ABI_VERSION:
+            # a stale build (or a VC_LIB_PATH override built from older sources) would take shifted pointer / size
+            # arguments: refuse it here instead of faulting on the device
+            raise VCError('native library %s reports ABI version %d, this binding is written for %d -- rebuild it '
+                          '(make -C speech-cloner_amd/csrc)' % (LIB_PATH, got, VC_ABI_VERSION))
         for name, (res, args) in _SIGS.items():
             fn = getattr(h, name)
             fn.restype = res

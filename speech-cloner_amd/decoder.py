@@ -68,6 +68,7 @@ class decoder_specs:
         c = self.cfg_d
         scope = c['model_name']
         self._scope = scope
+        modules._refuse_cudnn(c['use_Cudnn'], 'decoder_specs')
         if c['use_lstm'] and c['is_training']:
             raise NotImplementedError(' - ERROR, use_lstm is built for inference only (no shipped configuration uses it)')
         T, n_in = c['input_shape']
@@ -315,9 +316,26 @@ class decoder_specs:
         """decoder.py:349-376 without the TensorBoard writers: (mel_loss, stft_loss, loss)."""
         if summary_mode not in ('train', 'validation', 'test'):
             raise Exception(' - ERROR, summary_mode={} not implemented'.format(summary_mode))
+        c = self.cfg_d
+        if c['is_training']:
+            # the reference evaluates the graph it built (decoder.py:349-353): on a training model that is the
+            # train-mode forward (dropout and batch statistics active; bn's updates_collections=None moves the
+            # averages on every evaluation) -- the trainer's forward without the backward pass
+            x = self._to_device(inputs, self._input_width(), 'decoder input')
+            tm = self._to_device(target_mel, c['steps_v'][0]['n_output'], 'target_mel')
+            ts = self._to_device(target_stft, c['steps_v'][1]['n_output'], 'target_stft')
+            losses = self._get_trainer().forward_backward(x, tm, ts, backward=False)
+            mel_loss, stft_loss = (np.float32(v) for v in losses.cpu().numpy())
+            if c['loss_type'] == 'log':
+                loss = np.float32(np.log(mel_loss) + np.log(stft_loss))
+            elif c['loss_type'] == 'sum':
+                loss = np.float32(mel_loss + stft_loss)
+            else:
+                raise Exception('- ERROR, _build_loss, loss_type not understood.')
+            return mel_loss, stft_loss, loss
         tm = None
-        if self.cfg_d.get('use_target_mel_step2', False):
-            tm = self._to_device(target_mel, self.cfg_d['steps_v'][0]['n_output'], 'target_mel')
+        if c.get('use_target_mel_step2', False):
+            tm = self._to_device(target_mel, c['steps_v'][0]['n_output'], 'target_mel')
         o = self.forward(self._to_device(inputs, self._input_width(), 'decoder input'), tm)
         return self._losses(o, target_mel, target_stft)
 

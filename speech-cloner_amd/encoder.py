@@ -76,6 +76,7 @@ class encoder_spec_phn:
         """encoder.py:78-123: creates the variables (TF names) and the attribute handles."""
         if embed_size is None:
             embed_size = input_shape[-1]
+        modules._refuse_cudnn(use_Cudnn, 'encoder_spec_phn')
         if use_lstm and is_training:
             raise NotImplementedError(' - ERROR, use_lstm is built for inference only (no shipped configuration uses it)')
         self._embed_size = embed_size

@@ -472,9 +472,20 @@ def conv1d_banks(inputs, K=16, embed_size=256, is_training=True, scope="conv1d_b
     return (out, pooled) if pool_output == 'auto' else out
 
 
+def _refuse_cudnn(use_Cudnn, what):
+    """modules.py:188-197 / 227-236: with use_Cudnn the reference builds tf.contrib.cudnn_rnn.CudnnGRU / CudnnLSTM,
+    whose weights are ONE opaque parameter blob in cuDNN's own layout (and whose GRU applies the reset gate after the
+    recurrent product, unlike GRUCell).  Such a checkpoint cannot be restored into the GRUCell / LSTMCell variables
+    this package creates, and no shipped configuration sets it: refuse instead of silently building another model."""
+    if use_Cudnn:
+        raise NotImplementedError(' - ERROR, {}: use_Cudnn=True (cuDNN parameter blob / cell variant) is not built; '
+                                  'only the GRUCell / LSTMCell variable layout of use_Cudnn=False is supported'.format(what))
+
+
 def gru(inputs, num_units=None, bidirection=False, scope="gru", use_Cudnn=False, reuse=None):
     """modules.py:168-204: the x-halves of both directions' cell matmuls are one GEMM, the recurrence one
     persistent launch (bidirection=True is the only form CBHG uses; the unidirectional form is provided too)."""
+    _refuse_cudnn(use_Cudnn, 'gru')
     torch = _torch()
     store = _store()
     x = _as3(inputs)
@@ -531,6 +542,7 @@ def _prep_lstm(store, scope, cin, H, bidirection):
 def lstm(inputs, num_units=None, bidirection=False, scope="lstm", use_Cudnn=False, reuse=None):
     """modules.py:207-243: LSTMCell (no peepholes, forget_bias 1.0) under (bidirectional_)dynamic_rnn; the input
     halves of both directions are one GEMM, the recurrence one launch (vc_lstm_bidir).  Inference only."""
+    _refuse_cudnn(use_Cudnn, 'lstm')
     torch = _torch()
     store = _store()
     x = _as3(inputs)
@@ -663,6 +675,7 @@ def highway_chain(inputs, num_units, n_layers, scope_fmt='highwaynet_{}', gru_sc
 def CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dropout_rate=0.5, is_training=True,
          scope="CBHG", use_Cudnn=False, use_lstm=False, reuse=None):
     """modules.py:323-356.  [N, T, E/2] -> [N, T, E]."""
+    _refuse_cudnn(use_Cudnn, 'CBHG')
     if use_lstm and is_training:
         raise NotImplementedError(' - ERROR, CBHG: use_lstm is built for inference only (no shipped configuration sets it)')
     with variable_scope(scope):
@@ -755,6 +768,7 @@ def prenet_CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks
     recurrence as ONE launch (vc_cbhg_front: the layers are 40 channels wide, launch- and HBM-latency
     bound one by one); every other shape is prenet() + CBHG().  ``inputs`` may be float32 there (the
     conversion is part of the launch).  OPTIONS['cbhg_front'] = False switches the fused form off (A/B)."""
+    _refuse_cudnn(use_Cudnn, 'CBHG')
     torch = _torch()
     store = _store()
     x = _as3(inputs)

@@ -518,6 +518,19 @@ class StageTrainer:
             dX0 = self._dgrad_dense(dZ1, E, E, W1p, M, T_)
         return dX0
 
+    def _join_side(self):
+        """The current stream waits for everything this trainer issued to its side stream."""
+        if self._side is not None:
+            _torch().cuda.current_stream().wait_stream(self._side)
+
+    def _drain_pending(self):
+        """Buckets of an earlier forward_backward that no apply_gradients consumed (gradient accumulation, a retry
+        after an exception): wait for them before the arena is zeroed and written again."""
+        pending, self._pending = self._pending, []
+        for _, _, work in pending:
+            work.wait()
+        self._join_side()
+
     def _slice_of(self, prefix):
         """[lo, hi) of the arena covered by the variables under ``prefix`` (contiguous: creation order)."""
         offs = [self.offsets[n] for n in self.names if n.startswith(prefix)]
@@ -543,13 +556,17 @@ class StageTrainer:
         forward_backward already put on the wire are waited for; whatever they do not cover is summed here."""
         torch = _torch()
         c = self.cfg
-        _Ops.join()                                   # weight gradients still running on the side stream
-        if world > 1:
+        self._join_side()                             # weight gradients still running on the side stream
+        # whether there is anything to exchange is the process group's business, not the caller's argument: buckets
+        # already on the wire are always waited for; ``world`` only scales Adam (1 / world)
+        dist_world = torch.distributed.get_world_size() if (torch.distributed.is_available() and
+                                                             torch.distributed.is_initialized()) else 1
+        if dist_world > 1 or self._pending:
             pending, self._pending = self._pending, []
             covered = sorted((lo, hi) for lo, hi, _ in pending)
             pos = 0
             for lo, hi in covered + [(self.total, self.total)]:
-                if lo > pos:                                  # a stretch no bucket covered
+                if lo > pos and dist_world > 1:              # a stretch no bucket covered
                     torch.distributed.all_reduce(self.grad[pos:lo], op=torch.distributed.ReduceOp.SUM)
                 pos = max(pos, hi)
             for _, _, work in pending:
@@ -604,10 +621,14 @@ class DecoderTrainer(StageTrainer):
     opt_scope = 'dec_opt'
 
     # ---------------------------------------------------------------- whole step
-    def forward_backward(self, x, target_mel, target_stft):
-        """Forward + backward of one batch.  Returns the device tensor [mel_loss, stft_loss]."""
+    def forward_backward(self, x, target_mel, target_stft, backward=True):
+        """Forward + backward of one batch.  Returns the device tensor [mel_loss, stft_loss].
+        ``backward=False`` is the reference's exec_calc_metrics on a training graph (decoder.py:349-376): the
+        train-mode forward (dropout, batch statistics, moving averages move: updates_collections=None) and the two
+        losses; no gradient fill, no backward, no all-reduce."""
         torch = _torch()
         dec, c = self.dec, self.cfg
+        self._drain_pending()
         if c['loss_type'] not in ('sum', 'log'):
             raise Exception('- ERROR, _build_loss, loss_type not understood.')
         n_in = c['input_shape'][-1]
@@ -619,7 +640,8 @@ class DecoderTrainer(StageTrainer):
             ppg[:, :, :n_in] = x
         self.last_ppg = ppg
         M = ppg.shape[0] * ppg.shape[1]
-        _vc.check(_lib().vc_fill(_p(self.grad), 0.0, self.total, _st()))     # wgrad accumulates with atomics
+        if backward:
+            _vc.check(_lib().vc_fill(_p(self.grad), 0.0, self.total, _st()))     # wgrad accumulates with atomics
         sd1, sd2 = c['steps_v'][0], c['steps_v'][1]
         seed = self.seed + 1000 * self.step_count
         with modules.variable_store(self.store):
@@ -640,13 +662,15 @@ class DecoderTrainer(StageTrainer):
             self.y_mel = y1[:, :n1].contiguous() if y1.shape[1] != n1 else y1
             self.y_stft = y2[:, :n2].contiguous() if y2.shape[1] != n2 else y2
             # losses + output gradients (decoder.py:187-195)
-            dY1 = torch.zeros_like(y1)
-            dY2 = torch.zeros_like(y2)
+            dY1 = torch.zeros_like(y1) if backward else None
+            dY2 = torch.zeros_like(y2) if backward else None
             wm, ws = float(c['mel_loss_weight']), float(c['stft_loss_weight'])
             _vc.check(_lib().vc_mse_loss(_p(self.y_mel), _p(target_mel), M * n1, wm, _p(dY1), n1, y1.shape[1],
                                          _p(self.losses[0:1]), _p(self.loss_ws), _st()))
             _vc.check(_lib().vc_mse_loss(_p(self.y_stft), _p(target_stft), M * n2, ws, _p(dY2), n2, y2.shape[1],
                                          _p(self.losses[1:2]), _p(self.loss_ws), _st()))
+            if not backward:
+                return self.losses
             if c['loss_type'] == 'log':          # d log(L) = dL / L  (host round trip for the two scalars)
                 lm, ls = (float(v) for v in self.losses.cpu())
                 dY1.mul_(1.0 / lm)
@@ -663,9 +687,10 @@ class DecoderTrainer(StageTrainer):
                                           dY1.shape[1], _st()))
                 self._stage_backward(s1, sv1, dY1, need_dx=False)
                 self._start_allreduce(*self._slice_of(s1 + '/'))
-                _Ops.join()                           # whoever reads the gradient arena next finds it complete
             finally:
                 _Ops.side_stream = None
+                self._join_side()                     # whoever reads the gradient arena next finds it complete (also
+                                                      # after an exception: nothing keeps writing the arena)
         return self.losses
 
 
@@ -680,6 +705,7 @@ class EncoderTrainer(StageTrainer):
         """Returns the device tensor [loss, acc, mse]."""
         torch = _torch()
         enc, c = self.dec, self.cfg
+        self._drain_pending()
         N_, T_, Cx = x.shape
         M = N_ * T_
         n_out = c['n_output']
@@ -698,7 +724,7 @@ class EncoderTrainer(StageTrainer):
                 _Ops.side_stream = self._side
                 try:
                     self._stage_backward(enc._scope, sv, dY, need_dx=False)
-                    _Ops.join()
                 finally:
                     _Ops.side_stream = None
+                    self._join_side()
         return out3

@@ -68,7 +68,8 @@ def test_ctypes_signatures_follow_the_header_prototypes():
 def test_version_and_errors_without_gpu():
     import _vc
     lib = _vc.lib()
-    assert lib.vc_version() == 1
+    hdr = open(os.path.join(ROOT, 'include', 'vc_hip.h')).read()
+    assert int(re.search(r'#define\s+VC_ABI_VERSION\s+(\d+)', hdr).group(1)) == _vc.VC_ABI_VERSION == lib.vc_version()
     assert lib.vc_target_arch() == b'gfx950'
     # argument validation happens before any HIP call
     cfg = _vc.FrontendCfg(16000, 80, 400, 200, 80, 40, 0.97, 0.003, 0.01, 0.01, 0.01, 1, 1, 1)
@@ -166,3 +167,21 @@ def test_kernel_options_are_explicit_and_ablations_are_not_shipped():
     src = open(os.path.join(ROOT, 'speech-cloner_amd', 'modules.py')).read() + open(os.path.join(ROOT, 'speech-cloner_amd', '_vc.py')).read()
     assert 'os.environ[' not in src and 'environ.setdefault' not in src      # the package never writes the environment
     assert set(modules.OPTIONS) == {'prenet_chain', 'highway_chain', 'cbhg_front'}
+
+
+def test_a_library_of_another_abi_version_is_refused(tmp_path):
+    """include/vc_hip.h VC_ABI_VERSION: exported signatures changed between versions (arguments inserted in the middle),
+    so a stale build -- e.g. an old A/B library named by VC_LIB_PATH -- must be refused at load time, not called with
+    shifted pointers.  A stub library reporting version 1 stands in for the stale build (a separate interpreter: the
+    binding caches its handle)."""
+    import subprocess
+    import sys
+    src = tmp_path / 'stale.c'
+    src.write_text('int vc_version(void) { return 1; }\n')
+    so = tmp_path / 'libvc_stale.so'
+    subprocess.check_call(['gcc', '-shared', '-fPIC', str(src), '-o', str(so)])
+    code = ('import sys; sys.path.insert(0, %r); import _vc\n'
+            'try:\n    _vc.lib()\nexcept _vc.VCError as e:\n    print("REFUSED", e)\n' % os.path.join(ROOT, 'speech-cloner_amd'))
+    r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VC_LIB_PATH=str(so)), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and 'REFUSED' in r.stdout and 'ABI version 1' in r.stdout, r.stdout + r.stderr

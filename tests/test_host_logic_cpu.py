@@ -133,6 +133,28 @@ def test_model_objects_on_cpu_store(golden_dir, capsys):
         dec.exec_train_step(None, None, None)                      # built with is_training = False
 
 
+def test_use_cudnn_is_refused_not_ignored():
+    """modules.py:188-197, 227-236: use_Cudnn builds CudnnGRU / CudnnLSTM (one opaque parameter blob); a checkpoint of
+    such a model cannot be restored into the GRUCell / LSTMCell variables this package creates, so the constructors
+    and the recurrence wrappers refuse the flag instead of building another model behind the caller's back."""
+    from encoder import encoder_spec_phn
+    from decoder import decoder_specs
+    import modules
+    ec = json.load(open(os.path.join(HP, 'encoder_cfg_d.json')))
+    dc = json.load(open(os.path.join(HP, 'decoder_cfg_d.json')))
+    ec.update(is_training=False, device='cpu', use_Cudnn=True)
+    dc.update(is_training=False, device='cpu', use_Cudnn=True)
+    with pytest.raises(NotImplementedError, match='use_Cudnn'):
+        encoder_spec_phn(ec, None)
+    with pytest.raises(NotImplementedError, match='use_Cudnn'):
+        decoder_specs(dc, None, None)
+    for fn in (modules.gru, modules.lstm):
+        with pytest.raises(NotImplementedError, match='use_Cudnn'):
+            fn(None, num_units=8, bidirection=True, use_Cudnn=True)
+    with pytest.raises(NotImplementedError, match='use_Cudnn'):
+        modules.CBHG(None, use_Cudnn=True, is_training=False)
+
+
 def test_native_library_is_required():
     import _vc
     assert os.path.exists(_vc.LIB_PATH), 'libvc_hip.so must be built (no CPU fallback exists)'

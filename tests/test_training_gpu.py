@@ -234,6 +234,57 @@ def test_restore_resumes_adam_state_and_step(tmp_path, capsys):
     check(dec2, 'existing trainer')
 
 
+class _FakeDS:
+    """The two methods decoder.train() calls on its dataset (decoder.py:381-398), over fixed random batches."""
+
+    def __init__(self, n_windows, T):
+        self.n, self.T = n_windows, T
+
+    def get_n_windows(self, prop_val, **kw):
+        return self.n, 2
+
+    def spec_window_sampler(self, batch_size, n_epochs, randomize_samples, sample_trn, prop_val, **kw):
+        rng = np.random.RandomState(1 if sample_trn else 2)
+        while True:
+            yield (torch.softmax(torch.from_numpy(rng.standard_normal((batch_size, self.T, 61)) * 2), -1).float().numpy(),
+                   rng.uniform(0, 0.8, (batch_size, self.T, 80)).astype(np.float32),
+                   rng.uniform(0, 0.8, (batch_size, self.T, 201)).astype(np.float32))
+
+
+def test_train_loop_runs_through_a_save_epoch(tmp_path, monkeypatch, capsys):
+    """decoder.train() (decoder.py:379-444) on a tiny dataset: two steps per epoch, a checkpoint and a validation
+    batch every epoch -- the validation batch is evaluated on the TRAINING graph (decoder.py:349-353, 425-428), i.e.
+    through the trainer's forward without a backward pass -- two epochs, then 'End of Training'."""
+    import tf_bundle
+    from decoder import decoder_specs
+    cfg = _cfg()
+    cfg.update(model_path=str(tmp_path), batch_size=2, n_epochs=2, save_each_n_epochs=1, ds_prop_val=0.3,
+               randomize_samples=True)
+    dec = decoder_specs(cfg, _FakeDS(4, cfg['input_shape'][0]), None)
+    dec.store.load_dict(mo.init_weights(cfg, 'decoder', seed=5, perturb_bn=True))
+    monkeypatch.setattr('builtins.input', lambda *a: '')
+    dec.train()
+    out = capsys.readouterr().out
+    assert out.count('mel_loss_val=') == 2 and out.count('loss_trn=') == 4 and 'End of Training !!!' in out
+    assert dec.i_epoch == 2 and int(dec.opt_state['dec_opt/global_step']) == 4
+    ck = tf_bundle.read_bundle(tf_bundle.latest_checkpoint(str(tmp_path)))
+    assert int(ck['dec_opt/global_step']) == 4
+    # metrics on a training model: no gradient is written, no step is taken, the moving averages move
+    tr = dec._trainer
+    tr.grad.fill_(7.0)
+    mm = 'decoder/step1/CBHG/conv1d_1/moving_mean'
+    before = dec.store.vars[mm].clone()
+    rng = np.random.RandomState(5)
+    b = next(dec.ds.spec_window_sampler(2, 1, True, False, 0.3))
+    ml, sl, l = dec.exec_calc_metrics(*b)
+    assert np.isfinite(l) and abs(l - (ml + sl)) < 1e-5 * max(1.0, l)
+    assert float(tr.grad.min()) == 7.0 and tr.step_count == 4
+    assert not torch.equal(dec.store.vars[mm], before)
+    # and it is the train-mode forward: equal to forward_backward's losses on the same batch and dropout seed
+    ref = tr.forward_backward(*(torch.from_numpy(a).cuda() for a in b)).cpu().numpy()
+    assert abs(ref[0] - ml) < 1e-6 * max(1.0, ml)       # (moving averages do not enter the train-mode forward)
+
+
 def _hp_cfg(seed=77):
     import os
     from conftest import ROOT
