@@ -95,6 +95,26 @@ def time_events(fn, iters):
     return s.elapsed_time(e) / iters
 
 
+def _pmc_frontend_traffic():
+    tr = [_pmc_traffic(n) for n in ('fe400_stats_pass', 'fe400_feature_pass')]
+    return (tr[0] + tr[1]) if all(t is not None for t in tr) else None
+
+
+def frontend_kernel_figures(wav, out, iters):
+    """BASELINE configs[1] judged on bytes: the algorithmic 1,764 B/frame of the WHOLE front-end against the time of ALL
+    its launches (the statistics pass exists only because the normalisations need the utterance's extremes first;
+    crediting the bytes to the feature pass alone would flatter it).  HIP events around back-to-back launch sets."""
+    import audio_lib
+    B, L = wav.shape
+    frames = B * (1 + L // 80)
+    k = {}
+    for name, mask in (('stats_pass', 2), ('feature_pass', 4), ('all', 6)):
+        k[name] = time_events(lambda m=mask: audio_lib.calc_MFCC_input_batch(wav, None, out=out, stage_mask=m, **FE_KW), iters)
+    alg = FE_BYTES_PER_FRAME * frames
+    ach = alg / (k['all'] * 1e-3) / 1e9
+    return k, alg, ach, frames
+
+
 def bench_frontend(args, rank, world):
     import audio_lib
     B, L = 32, 64000
@@ -124,20 +144,11 @@ def bench_frontend(args, rank, world):
     extra = {}
     if rank == 0:
         iters = max(50, args.steps)
-        k = {}
-        for name, mask in (('stats_pass', 2), ('feature_pass', 4), ('all', 6)):
-            k[name] = time_events(lambda m=mask: audio_lib.calc_MFCC_input_batch(
-                wav, None, out=out, stage_mask=m, **FE_KW), iters)
-        alg = FE_BYTES_PER_FRAME * frames
-        # Judged on bytes: the algorithmic 1,764 B/frame of the WHOLE front-end against the time of BOTH launches (the
-        # statistics pass exists only because the normalisations need the utterance's extremes first; crediting all the
-        # bytes to the feature pass alone would flatter it).  HIP events around back-to-back pairs of launches.
-        ach = alg / (k['all'] * 1e-3) / 1e9
-        tr = [_pmc_traffic(n) for n in ('fe400_stats_pass', 'fe400_feature_pass')]
+        k, alg, ach, _ = frontend_kernel_figures(wav, out, iters)
         extra['roofline'] = {'kernel': 'fe400_kernel<false> (feature pass, dominant) + fe400_kernel<true> (statistics pass)',
                              'bound': 'hbm', 'achieved': round(ach, 1),
                              'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4),
-                             'traffic': (tr[0] + tr[1]) if all(t is not None for t in tr) else None,
+                             'traffic': _pmc_frontend_traffic(),
                              'algorithmic_bytes_per_launch': alg,
                              'avg_kernel_ms': round(k['all'], 5),
                              'timing': 'HIP events on the launch stream, average of %d back-to-back launch pairs' % iters,
@@ -149,6 +160,20 @@ def bench_frontend(args, rank, world):
                            'frontend_pipeline_GBps': round(alg / (k['all'] * 1e-3) / 1e9, 1)}
     return frames, dt, extra, {'workload': 'frontend: STFT+mel+MFCC, batch 32 x 4 s @ 16 kHz (BASELINE configs[1])',
                                'batch': B, 'samples': L, 'frames_per_step_per_gpu': frames}
+
+
+def frontend_side_measurement(wav):
+    """BASELINE configs[1] inside the default line (rank 0): the front-end alone on the same resident 32 x 4 s batch,
+    every frame stored (25,632 frames), HIP events over 50 back-to-back launch sets."""
+    import audio_lib
+    out = audio_lib.calc_MFCC_input_batch(wav, None, **FE_KW)
+    k, alg, ach, frames = frontend_kernel_figures(wav, out, 50)
+    return {'workload': 'BASELINE configs[1]: STFT+mel+MFCC on %d x 4 s @ 16 kHz, float32, %d frames' % (wav.shape[0], frames),
+            'ms': round(k['all'], 5), 'stats_pass_ms': round(k['stats_pass'], 5), 'feature_pass_ms': round(k['feature_pass'], 5),
+            'frames_per_s': round(frames / (k['all'] * 1e-3), 1),
+            'GBps': round(ach, 1), 'frac': round(ach / HBM_PEAK_GBS, 4), 'peak_GBps': HBM_PEAK_GBS,
+            'algorithmic_bytes': alg, 'traffic': _pmc_frontend_traffic(),
+            'timing': 'HIP events on the launch stream, 50 back-to-back launch sets (all launches of the front-end)'}
 
 
 def load_models(dtype, rank):
@@ -337,7 +362,7 @@ def bench_full(args, rank, world):
     # the reference's own precision (float32 arithmetic end to end, exact-f32 MFMA), same workload and pipeline, in the
     # same driver-observed line; every rank runs it so that ranks stay in step, rank 0 reports its own figure
     if args.dtype == 'bfloat16' and not args.no_f32:
-        del pipe
+        pipe = None
         torch.cuda.empty_cache()
         enc32, dec32 = load_models('float32', rank)
         pipe32 = _Pipeline(wav, dec32, args.window_batch, min(args.streams, 4))
@@ -349,6 +374,16 @@ def bench_full(args, rank, world):
                             'steps': k32, 'what': 'same step with float32 weights / activations / accumulation (the '
                                                   "reference's arithmetic type), %d streams" % min(args.streams, 4)}
         del pipe32, enc32, dec32
+        torch.cuda.empty_cache()
+    # BASELINE configs[1] (front-end alone) and configs[4] (training step) in the same driver-observed line
+    if not args.no_side:
+        if rank == 0:
+            extra['frontend'] = frontend_side_measurement(wav)
+        pipe = enc = dec = None
+        torch.cuda.empty_cache()
+        tr_line = train_side_measurement(rank, world, 'cpu' if args.backend == 'gloo' else 'cuda')
+        if rank == 0:
+            extra['train'] = tr_line
     cfg = {'workload': 'full: STFT+mel front-end on batch %d x 4 s @ 16 kHz (configs[1] input) -> %d windows of 400 '
                        'frames -> encoder (enc_14 weights) + decoder (hp/decoder_cfg_d.json sizes, random init), '
                        '%d windows per launch, independent steps pipelined over %d HIP streams' % (B, nwin, args.window_batch, args.streams),
@@ -357,13 +392,24 @@ def bench_full(args, rank, world):
     return frames, dt, extra, cfg
 
 
-def bench_train(args, rank, world):
-    """BASELINE configs[4]: decoder training step (fwd + bwd + Adam, float32) on synthetic
-    ARCTIC-slt-shaped targets, 32 windows per GPU, gradients all-reduced over RCCL."""
+def rccl_info(backend):
+    """What the collective library is, for the day the line is produced on more than one GPU."""
+    info = {'backend': backend, 'ranks': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1}
+    try:
+        info['version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())        # RCCL reports through torch's nccl module
+    except Exception as e:                                                          # pragma: no cover
+        info['version'] = 'unavailable: %s' % e
+    return info
+
+
+def train_measure(rank, world, steps, warmup):
+    """BASELINE configs[4] per-GPU shape: `steps` decoder training steps (fwd + bwd + Adam, float32, 32 windows x 400
+    frames; under data parallelism the two gradient buckets are all-reduced, overlapped with the backward pass) timed
+    wall-clock between barriers + synchronize; then the exchange alone (whole arena and bucket by bucket, HIP events)
+    and, on rank 0, the dominant kernel.  Returns (frames per step, seconds, stages dict, roofline dict or None)."""
     import contextlib
     import io
     B, T = 32, 400
-    enc, dec = None, None
     with contextlib.redirect_stdout(io.StringIO()):
         from aux_func import load_cfg_d
         from encoder import encoder_spec_phn
@@ -380,37 +426,48 @@ def bench_train(args, rank, world):
     mel = (torch.rand(B, T, 80, generator=g) * 0.8).cuda()
     stft = (torch.rand(B, T, 201, generator=g) * 0.8).cuda()
     last = None
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         last = dec.exec_train_step(mfcc, mel, stft)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         last = dec.exec_train_step(mfcc, mel, stft)
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
     dt = time.perf_counter() - t0
     tr = dec._trainer
-    # the one exchange step of the path, alone: all-reduce of the flat gradient arena (every rank takes part)
-    ar_ms = None
+    # the one exchange step of the path, alone: all-reduce of the flat gradient arena (every rank takes part), and the
+    # two buckets forward_backward puts on the wire (stage 2 first, under stage 1's backward)
+    ar_ms, buckets = None, None
     if world > 1:
-        torch.distributed.barrier()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            torch.distributed.all_reduce(tr.grad, op=torch.distributed.ReduceOp.SUM)
-        e1.record()
-        torch.cuda.synchronize()
-        ar_ms = e0.elapsed_time(e1) / 5
-    extra = {'stages': {'last_loss': float(last[2]), 'global_step': int(last[3]),
-                        'params': int(tr.total), 'allreduce_MB': round(tr.total * 4 / 1e6, 1),
-                        'allreduce_ms': None if ar_ms is None else round(ar_ms, 4),
-                        'allreduce_busbw_GBps': None if ar_ms is None else
-                        round(2.0 * (world - 1) / world * tr.total * 4 / (ar_ms * 1e-3) / 1e9, 1)}}
+        def timed_allreduce(t):
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / 5
+        ar_ms = timed_allreduce(tr.grad)
+        buckets = []
+        for st_ in ('step2', 'step1'):
+            lo, hi = tr._slice_of('%s/%s/' % (dec._scope, st_))
+            ms = timed_allreduce(tr.grad[lo:hi])
+            buckets.append({'bucket': st_, 'MB': round((hi - lo) * 4 / 1e6, 1), 'allreduce_ms': round(ms, 4),
+                            'busbw_GBps': round(2.0 * (world - 1) / world * (hi - lo) * 4 / (ms * 1e-3) / 1e9, 1)})
+    stages = {'last_loss': float(last[2]), 'global_step': int(last[3]),
+              'params': int(tr.total), 'allreduce_MB': round(tr.total * 4 / 1e6, 1),
+              'allreduce_ms': None if ar_ms is None else round(ar_ms, 4),
+              'allreduce_busbw_GBps': None if ar_ms is None else
+              round(2.0 * (world - 1) / world * tr.total * 4 / (ar_ms * 1e-3) / 1e9, 1),
+              'allreduce_buckets': buckets}
+    roof = None
     if rank == 0:
         import modules
         # dominant kernel of the step: conv_kernel<float> on the step-2 filter bank (forward; the data- and
@@ -421,15 +478,45 @@ def bench_train(args, rank, world):
             ms_bank = time_events(lambda: modules.conv1d_banks(pre, K=32, is_training=False), 20)
         fl_bank = 2.0 * 256 * 128 * 528 * B * T
         ach = fl_bank / (ms_bank * 1e-3) / 1e12
-        extra['roofline'] = {'kernel': 'conv_kernel<float> (decoder step2 conv1d_banks forward, exact-f32 MFMA)', 'bound': 'mfma',
-                             'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
-                             'frac': round(ach / MFMA_F32_PEAK_TF, 4), 'traffic': None,
-                             'algorithmic_flop_per_launch': fl_bank, 'avg_kernel_ms': round(ms_bank, 4),
-                             'timing': 'HIP events on the launch stream, average of 20 back-to-back launches'}
-        extra['stages']['step_TFLOPs_at_3x_forward'] = round(3 * DEC_FLOP_PER_FRAME * B * T / (dt / args.steps) / 1e12, 1)
+        roof = {'kernel': 'conv_kernel<float> (decoder step2 conv1d_banks forward, exact-f32 MFMA)', 'bound': 'mfma',
+                'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
+                'frac': round(ach / MFMA_F32_PEAK_TF, 4), 'traffic': None,
+                'algorithmic_flop_per_launch': fl_bank, 'avg_kernel_ms': round(ms_bank, 4),
+                'timing': 'HIP events on the launch stream, average of 20 back-to-back launches'}
+        stages['step_TFLOPs_at_3x_forward'] = round(3 * DEC_FLOP_PER_FRAME * B * T / (dt / steps) / 1e12, 1)
+        stages['step_frac_of_f32_mfma_peak'] = round(stages['step_TFLOPs_at_3x_forward'] / MFMA_F32_PEAK_TF, 4)
+    del dec, enc, tr
+    torch.cuda.empty_cache()
+    return B * T, dt, stages, roof
+
+
+def bench_train(args, rank, world):
+    """BASELINE configs[4]: decoder training step (fwd + bwd + Adam, float32) on synthetic
+    ARCTIC-slt-shaped targets, 32 windows per GPU, gradients all-reduced over RCCL."""
+    frames, dt, stages, roof = train_measure(rank, world, args.steps, args.warmup)
+    extra = {'stages': stages}
+    if roof is not None:
+        extra['roofline'] = roof
     cfg = {'workload': 'train: decoder fwd+bwd+Adam (float32) on 32 windows x 400 frames per GPU, encoder frozen '
-                       '(BASELINE configs[4])', 'global_batch': B * world, 'frames_per_step_per_gpu': B * T}
-    return B * T, dt, extra, cfg
+                       '(BASELINE configs[4])', 'global_batch': 32 * world, 'frames_per_step_per_gpu': frames}
+    return frames, dt, extra, cfg
+
+
+def train_side_measurement(rank, world, reduce_device='cuda'):
+    """BASELINE configs[4] inside the default line: 10 training steps after 3 warm-ups on every rank (the gradient
+    exchange is a collective), max over ranks; rank 0 reports."""
+    import dist_util
+    steps, warmup = 10, 3
+    frames, dt, stages, roof = train_measure(rank, world, steps, warmup)
+    dt = dist_util.max_over_ranks(dt, device=reduce_device) if world > 1 else dt
+    return {'workload': 'BASELINE configs[4] per-GPU shape: decoder fwd+bwd+Adam, float32, 32 windows x 400 frames per GPU, '
+                        'encoder frozen; data parallel x%d' % world,
+            'ms_per_step': round(dt / steps * 1e3, 4), 'steps': steps, 'warmup': warmup,
+            'frames_per_s': round(frames * world * steps / dt, 1), 'step_TFLOPs': stages.get('step_TFLOPs_at_3x_forward'),
+            'step_frac_of_f32_mfma_peak': stages.get('step_frac_of_f32_mfma_peak'),
+            'roofline': None if roof is None else {k: roof[k] for k in ('kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_kernel_ms')},
+            'allreduce_ms': stages['allreduce_ms'], 'allreduce_busbw_GBps': stages['allreduce_busbw_GBps'],
+            'allreduce_buckets': stages['allreduce_buckets'], 'last_loss': stages['last_loss']}
 
 
 def bench_vocoder(args, rank, world):
@@ -670,6 +757,8 @@ def main(argv=None):
                     help='process-group backend (default: nccl = RCCL; the stub workload uses gloo)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-f32', action='store_true', help='skip the float32 side measurement of the full workload')
+    ap.add_argument('--no-side', action='store_true',
+                    help='skip the front-end-alone and training-step side measurements of the full workload')
     args = ap.parse_args(argv)
     if args.gpus < 1:
         raise SystemExit('bench.py: --gpus must be >= 1')
@@ -718,6 +807,8 @@ def main(argv=None):
                 ('bf16' if args.dtype == 'bfloat16' else 'f32'), 'data': 'synthetic',
                 'config': dict(cfg, parallelism=par)}
         line.update(extra)
+        if not stub:
+            line['rccl'] = rccl_info(backend)
         if joined == 1 and not args.no_cpu_baseline and not stub:
             line['cpu_baseline'] = {'frontend': cpu_baseline_frontend, 'vocoder': cpu_baseline_vocoder,
                                     'train': cpu_baseline_train}.get(args.workload, cpu_baseline_full)()

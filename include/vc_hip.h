@@ -37,8 +37,9 @@ extern "C" {
 
 /* 2: vc_frontend_f32 / vc_frontend_stages_f32 take out_rows, vc_transpose_pad takes slack_row, vc_gemm_desc has
  *    sum_groups.  Bump on EVERY change of an exported signature or struct layout: the Python binding (_vc.py) refuses
- *    to load a library whose vc_version() differs from its own constant. */
-#define VC_ABI_VERSION 2
+ *    to load a library whose vc_version() differs from its own constant.
+ * 3: vc_gemm_desc ends with d_workspace / workspace_bytes (vc_conv_gemm_workspace_bytes); vc_bn_post_routing added. */
+#define VC_ABI_VERSION 3
 
 int vc_version(void);
 const char* vc_last_error(void);
@@ -54,6 +55,7 @@ const char* vc_target_arch(void);
  *   "conv256_min_k"  shortest K that takes conv256_kernel (default 384)
  *   "conv256_wm"     2 = keep 128-row blocks for 128-column launches
  *   "proj256"        0 = the 256-channel k = 3 projection on conv256_kernel instead of the bank tiles
+ *   "proj256_split"  0 = never split that projection's K over two workgroups per row tile (see d_workspace)
  *   "wgrad_xcd"      0 = weight-gradient tiles dealt round-robin to the XCDs
  *   "gru_mfma"       0 = VALU recurrence always, 1 = MFMA recurrence always (default: from 32 sequences up)
  *   "prenet_lds"     0 = every wave of the fused prenet streams the weights from L2 itself (default: one stream per
@@ -238,9 +240,17 @@ typedef struct vc_gemm_desc {
                                     * its value) = tf.layers.max_pooling1d(2, 1, 'same') of the result, fused into the
                                     * producer (modules.py:331 after :329).  Needs act = ReLU and a launch for which
                                     * vc_conv_gemm_epi_pool_supported() returns 1; vc_conv_gemm rejects it otherwise. */
+    void* d_workspace;             /* optional scratch for launches that split K over workgroups (today: the 256-channel
+                                    * long-K projection on the bank tiles when its row tiles alone would leave most CUs
+                                    * idle): vc_conv_gemm_workspace_bytes() says how much such a launch wants (0: none).
+                                    * 256-byte aligned, private to the call until it has finished on its stream (contents
+                                    * need not be initialised).  NULL or too small: the unsplit form runs, same result. */
+    size_t workspace_bytes;
 } vc_gemm_desc;
 
 int vc_conv_gemm(const vc_gemm_desc* desc, void* stream);
+/* Bytes of d_workspace the launch described by `desc` can use (0 for nearly all launches; d_workspace itself is ignored). */
+size_t vc_conv_gemm_workspace_bytes(const vc_gemm_desc* desc);
 /* 1 if `desc` (with epi_pool set) can run with the pooled epilogue: the bf16 filter-bank launch that
  * maps onto the paired 256-row tiles (tiles then overlap by one frame), else 0.  Host-only. */
 int vc_conv_gemm_epi_pool_supported(const vc_gemm_desc* desc);
@@ -331,6 +341,14 @@ int vc_bn_backward(const float* d_G, const float* d_X, int32_t M, int32_t C, int
                    const float* d_gamma, const float* d_scale, const float* d_shift, const float* d_mean,
                    const float* d_rstd, int32_t mode, float* d_dX, float* d_dgamma, float* d_dbeta,
                    float* d_workspace, void* stream);
+/* The relu / max-pool routing vc_bn_backward(mode 2) applies (modules.py:165 relu, :331 max_pooling1d(2, 1, same)), one
+ * byte per element of X [M, C] (output contiguous, row stride C): bit 0: bn(X) > 0; bit 1: the element receives the
+ * gradient of its own frame's pool output (last frame of a window, or >= its successor); bit 2: it receives the
+ * previous frame's (strictly greater than its predecessor).  Same device function as the backward pass itself; where
+ * two float32 pre-activations tie to within rounding TensorFlow's float32 kernels would be equally arbitrary, so a
+ * float64 restatement has to be handed these decisions to be comparable element by element (tests). */
+int vc_bn_post_routing(const float* d_X, int32_t M, int32_t C, int32_t ld, int32_t T, const float* d_scale,
+                       const float* d_shift, uint8_t* d_bits, void* stream);
 /* dZ = (Y > 0) ? dY * inv_keep : 0 for Y = dropout(relu(Z)) (modules.py:291-294). */
 int vc_relu_dropout_backward(const float* d_dY, const float* d_Y, float inv_keep, float* d_dZ, size_t n, void* stream);
 /* highwaynet backward gate arithmetic (modules.py:315-318) on re-computed pre-activations in the

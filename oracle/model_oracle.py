@@ -47,11 +47,13 @@ BN_DECAY = 0.999
 
 
 # --------------------------------------------------------------------------- building blocks
-def dense(x, w, scope, act=None):
-    """tf.layers.dense(x, units, activation, name=scope) (modules.py:291-293,315-317)."""
+def dense(x, w, scope, act=None, relu_on=None):
+    """tf.layers.dense(x, units, activation, name=scope) (modules.py:291-293,315-317).
+    ``relu_on``: GIVEN routing of a relu (0/1 tensor of the output's shape: y * relu_on instead of max(y, 0)); see
+    conv1d_banks."""
     y = x @ w[scope + '/kernel'] + w[scope + '/bias']
     if act == 'relu':
-        y = torch.relu(y)
+        y = torch.relu(y) if relu_on is None else y * relu_on
     elif act == 'sigmoid':
         y = torch.sigmoid(y)
     return y
@@ -66,11 +68,11 @@ def dropout(x, rate, mask=None):
     return x / keep * mask
 
 
-def prenet(x, w, scope, dropout_rate=0.5, masks=None):
-    """modules.py:274-295.  masks = (mask1, mask2) or None."""
-    y = dense(x, w, scope + '/dense1', 'relu')
+def prenet(x, w, scope, dropout_rate=0.5, masks=None, relu_on=None):
+    """modules.py:274-295.  masks = (mask1, mask2) or None.  relu_on = (on1, on2) or None: given relu routing."""
+    y = dense(x, w, scope + '/dense1', 'relu', None if relu_on is None else relu_on[0])
     y = dropout(y, dropout_rate, None if masks is None else masks[0])
-    y = dense(y, w, scope + '/dense2', 'relu')
+    y = dense(y, w, scope + '/dense2', 'relu', None if relu_on is None else relu_on[1])
     y = dropout(y, dropout_rate, None if masks is None else masks[1])
     return y
 
@@ -106,11 +108,15 @@ def bn(x, w, scope, is_training=False, stats_out=None):
     return (x - mean) * torch.rsqrt(var + BN_EPS) * gamma + beta
 
 
-def conv1d_banks(x, w, scope, K, is_training=False, stats_out=None, taps=None):
+def conv1d_banks(x, w, scope, K, is_training=False, stats_out=None, taps=None, relu_on=None):
     """modules.py:144-166: K convs of width 1..K (each 128 filters in every shipped model --
     called without embed_size at modules.py:328), concat, bn, relu.
-    ``taps``: optional dict that receives 'banks_pre', the normalised pre-activations (tests use them to
-    tell which channels have a frame sitting on the relu kink)."""
+    ``taps``: optional dict that receives 'banks_pre', the normalised pre-activations.
+    ``relu_on``: optional 0/1 tensor of the output's shape -- GIVEN routing: the relu passes exactly these elements
+    (pre * relu_on instead of max(pre, 0)).  A float32 kernel and this float64 restatement legitimately disagree about
+    the side of the kink for the handful of pre-activations that lie within float32 rounding of zero; with the
+    device's own decisions handed in, values change by at most that rounding and the gradients follow the same route
+    on both sides, so they can be compared channel by channel without excuses."""
     outs = [conv1d(x, w[scope + '/conv1d/conv1d/kernel'])]
     for k in range(2, K + 1):
         outs.append(conv1d(x, w[scope + '/num_%d/conv1d/conv1d/kernel' % k]))
@@ -118,18 +124,28 @@ def conv1d_banks(x, w, scope, K, is_training=False, stats_out=None, taps=None):
     pre = bn(y, w, scope + '/bn', is_training, stats_out)
     if taps is not None:
         taps['banks_pre'] = pre.detach()
+    if relu_on is not None:
+        return pre * relu_on
     return torch.relu(pre)
 
 
-def max_pool_2_same(x):
-    """tf.layers.max_pooling1d(pool_size=2, strides=1, padding='same') (modules.py:331)."""
+def max_pool_2_same(x, winners=None):
+    """tf.layers.max_pooling1d(pool_size=2, strides=1, padding='same') (modules.py:331).
+    ``winners`` = (own, prev), optional 0/1 tensors of x's shape -- GIVEN routing: own[t] says x[t] is the maximum of
+    its own output frame t, prev[t] says x[t] is the maximum of output frame t - 1; out[t] = x[t] own[t] +
+    x[t+1] prev[t+1].  Exactly one of the two is set wherever either operand is positive (both clear where the
+    output is 0), so the value equals the maximum up to the rounding that made the decision arbitrary."""
+    if winners is not None:
+        own, prev = winners
+        nxt = x * prev
+        return x * own + torch.cat([nxt[:, 1:], torch.zeros_like(nxt[:, :1])], dim=1)
     nxt = torch.cat([x[:, 1:], x[:, -1:]], dim=1)
     return torch.maximum(x, nxt)
 
 
-def highwaynet(x, w, scope):
-    """modules.py:297-319."""
-    H = dense(x, w, scope + '/dense1', 'relu')
+def highwaynet(x, w, scope, relu_on=None):
+    """modules.py:297-319.  relu_on: given routing of dense1's relu (see dense)."""
+    H = dense(x, w, scope + '/dense1', 'relu', relu_on)
     Tg = dense(x, w, scope + '/dense2', 'sigmoid')
     return H * Tg + x * (1.0 - Tg)
 
@@ -187,14 +203,28 @@ def lstm_bidirectional(x, w, scope):
     return torch.cat([fw, bw], dim=2)
 
 
-def cbhg(x, w, scope, K, n_highway, is_training=False, stats_out=None, taps=None):
-    """modules.py:323-356.  ``taps``: optional dict that receives intermediate tensors."""
-    y = conv1d_banks(x, w, scope + '/conv1d_banks', K, is_training, stats_out, taps=taps)
+def routing_from_bits(bits, dtype=torch.float64):
+    """Unpack vc_bn_post_routing's bytes (include/vc_hip.h: bit 0 relu passes, bit 1 winner of its own pool frame,
+    bit 2 winner of the previous frame's) into the (relu_on, own, prev) tensors conv1d_banks / max_pool_2_same take."""
+    b = torch.as_tensor(bits).to(torch.uint8)
+    return tuple(((b >> k) & 1).to(dtype) for k in range(3))
+
+
+def cbhg(x, w, scope, K, n_highway, is_training=False, stats_out=None, taps=None, routing=None):
+    """modules.py:323-356.  ``taps``: optional dict that receives intermediate tensors.  ``routing``: optional dict of
+    GIVEN relu / max-pool decisions (see conv1d_banks): 'banks' -> (relu_on, own, prev) for the filter bank's relu and
+    the max-pool behind it, 'conv1d_1' -> relu_on of the first projection's relu, 'highway' -> list of relu_on, one
+    per highway block; a missing key leaves that layer to its own max(x, 0)."""
+    routing = routing or {}
+    rb = routing.get('banks')
+    y = conv1d_banks(x, w, scope + '/conv1d_banks', K, is_training, stats_out, taps=taps,
+                     relu_on=None if rb is None else rb[0])
     if taps is not None:
         taps['banks'] = y
-    y = max_pool_2_same(y)
+    y = max_pool_2_same(y, None if rb is None else rb[1:])
     y = conv1d(y, w[scope + '/conv1d_1/conv1d/kernel'])
-    y = torch.relu(bn(y, w, scope + '/conv1d_1', is_training, stats_out))
+    y = bn(y, w, scope + '/conv1d_1', is_training, stats_out)
+    y = torch.relu(y) if routing.get('conv1d_1') is None else y * routing['conv1d_1']
     if taps is not None:
         taps['proj1'] = y
     y = conv1d(y, w[scope + '/conv1d_2/conv1d/kernel'])
@@ -203,7 +233,7 @@ def cbhg(x, w, scope, K, n_highway, is_training=False, stats_out=None, taps=None
     if taps is not None:
         taps['proj2_res'] = y
     for i in range(n_highway):
-        y = highwaynet(y, w, scope + '/highwaynet_%d' % i)
+        y = highwaynet(y, w, scope + '/highwaynet_%d' % i, None if routing.get('highway') is None else routing['highway'][i])
     if taps is not None:
         taps['highway'] = y
     if (scope + '/lstm/bidirectional_rnn/fw/lstm_cell/kernel') in w:          # use_lstm (modules.py:347-350)
@@ -230,11 +260,13 @@ def encoder_forward(x, w, cfg, scope=None, taps=None, is_training=False, masks=N
 
 
 def decoder_forward(ppg, w, cfg, is_training=False, masks=None, stats_out=None, taps=None, target_mel=None,
-                    f_mel_pred=None):
+                    f_mel_pred=None, routing=None):
     """decoder.py:75-182.  ppg = encoder softmax [N,T,61].
     ``masks``: dict 'step1'/'step2' -> (mask1, mask2) dropout keep-masks for training.
     ``target_mel`` / ``f_mel_pred``: with cfg['use_target_mel_step2'] the second stage is fed
     f_mel_pred * y_mel + (1 - f_mel_pred) * target_mel (decoder.py:148-152).
+    ``routing``: optional dict 'step1'/'step2' -> dict of given relu / pool decisions: 'prenet' -> (on1, on2) and the keys
+    cbhg takes ('banks', 'conv1d_1', 'highway').
     Returns (y_mel, y_stft)."""
     scope = cfg.get('model_name', 'decoder')
     x = ppg
@@ -242,14 +274,15 @@ def decoder_forward(ppg, w, cfg, is_training=False, masks=None, stats_out=None, 
     for i, sd in enumerate(cfg['steps_v']):
         s = '%s/step%d' % (scope, i + 1)
         m = None if masks is None else masks['step%d' % (i + 1)]
-        pre = prenet(x, w, s + '/prenet', cfg['dropout_rate'], m)
+        rt = {} if routing is None else routing.get('step%d' % (i + 1), {})
+        pre = prenet(x, w, s + '/prenet', cfg['dropout_rate'], m, rt.get('prenet'))
         t = None
         if taps is not None:
             t = {}
             taps['step%d' % (i + 1)] = t
             t['prenet'] = pre
         out = cbhg(pre, w, s + '/CBHG', sd['num_conv_banks'], sd['num_highwaynet_blocks'],
-                   is_training, stats_out, taps=t)
+                   is_training, stats_out, taps=t, routing=rt)
         if t is not None:
             t['cbhg'] = out
         y = dense(out, w, s + '/y_logits')

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VC_LIB_PATH', os.path.join(_HERE, 'libvc_hip.so'))   # override: kernel A/B experiments
 
 VC_OK = 0
-VC_ABI_VERSION = 2      # include/vc_hip.h: VC_ABI_VERSION -- lib() refuses a library that reports another one
+VC_ABI_VERSION = 3      # include/vc_hip.h: VC_ABI_VERSION -- lib() refuses a library that reports another one
 
 
 class VCError(RuntimeError):
@@ -59,7 +59,8 @@ class GemmDesc(C.Structure):
                 ('d_epi_scale', C.c_void_p), ('d_epi_shift', C.c_void_p), ('act', C.c_int32),
                 ('d_R', C.c_void_p), ('ldr', C.c_int32), ('d_C', C.c_void_p), ('ldc', C.c_int32),
                 ('out_f32', C.c_int32), ('drop_keep', C.c_float), ('drop_seed', C.c_ulonglong),
-                ('sum_groups', C.c_int32), ('epi_pool', C.c_int32)]
+                ('sum_groups', C.c_int32), ('epi_pool', C.c_int32),
+                ('d_workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
 CBHG_FRONT_MAX_HIGHWAY = 4
@@ -120,6 +121,7 @@ _SIGS = {
                                   C.c_size_t, _P]),
     'vc_frontend_stages_f32': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P,
                                          C.c_size_t, _P, C.c_int32]),
+    'vc_conv_gemm_workspace_bytes': (C.c_size_t, [C.POINTER(GemmDesc)]),
     'vc_conv_gemm': (C.c_int, [C.POINTER(GemmDesc), _P]),
     'vc_softmax_argmax': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, C.c_int32, _P, _P]),
     'vc_softmax_argmax_dual': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, _P]),
@@ -137,6 +139,7 @@ _SIGS = {
     'vc_affine_act': (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_size_t, C.c_int32, _P]),
     'vc_bn_backward': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P,
                                  C.c_int32, _P, _P, _P, _P, _P]),
+    'vc_bn_post_routing': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     'vc_relu_dropout_backward': (C.c_int, [_P, _P, C.c_float, _P, C.c_size_t, _P]),
     'vc_highway_backward': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     'vc_col_sum': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),

@@ -64,8 +64,16 @@ bank256_kernel(Bank256Args a) {
     // Block -> (pair, row tile).  XCD-aware form: workgroup ids go round-robin to the 8 XCDs, so id & 7
     // names the XCD; the launcher gives every XCD a short list of (pair, row-tile range) segments so that a
     // pair's weight stream (up to 4 MB) is fetched into one or two L2s instead of eight (see vc_launch_bank256).
-    int psel, rt;
-    if (a.xcd_tiles > 0) {
+    int psel, rt, ks = 0;
+    if (a.ksplit > 1) {
+        // split K: ids b and b + 8 share an XCD (round-robin placement: speed only), so the ksplit workgroups of a row
+        // tile are consecutive multiples of 8 apart -- dispatched together, finishing together, exchanging through one L2
+        const int q = blockIdx.x >> 3;
+        ks = q % a.ksplit;
+        rt = (q / a.ksplit) * 8 + (blockIdx.x & 7);
+        psel = 0;
+        if (rt * BM >= a.M) return;
+    } else if (a.xcd_tiles > 0) {
         const int xcd = blockIdx.x & 7;
         int slot = blockIdx.x >> 3;
         psel = -1; rt = 0;
@@ -83,7 +91,9 @@ bank256_kernel(Bank256Args a) {
     const Bank256Pair pr = a.p[psel];
     const int m0 = rt * (a.pool ? BM - 1 : BM);            // pooled output: tiles overlap by one frame
     const int ntap = pr.taps0 + pr.extra;              // taps of the wider filter
-    const int nslab = a.Cin >> 6;
+    const int nslab_all = a.Cin >> 6;
+    const int cs0 = ks * nslab_all / a.ksplit;         // this workgroup's channel slabs [cs0, cs0 + nslab)
+    const int nslab = (ks + 1) * nslab_all / a.ksplit - cs0;
     const int ntiles = nslab * ntap;
     const int pad_l = pr.pad_l;
     const __bf16* X = reinterpret_cast<const __bf16*>(a.X);
@@ -98,7 +108,7 @@ bank256_kernel(Bank256Args a) {
         const int rho = (q * 8 + wid) * 8 + srow;
         const int g = min(max(m0 - pad_l + rho, 0), a.M - 1);
         const int slot = pslot ^ ((rho >> 1) & 7);
-        a_src[q] = X + (size_t)g * a.ldx + slot * 8;
+        a_src[q] = X + (size_t)g * a.ldx + slot * 8 + cs0 * 64;
     }
     const int a_rows_needed = BM + ntap - 1;           // rows >= this are never read
     // B: row block rb = q*8 + wid (q = 0..3), row n = rb*8 + srow; n < 128 -> narrower filter
@@ -110,7 +120,7 @@ bank256_kernel(Bank256Args a) {
         const bool left = n < 128;
         const __bf16* Bt = reinterpret_cast<const __bf16*>(left ? pr.Bt0 : pr.Bt1);
         const int K = (left ? pr.taps0 : ntap) * a.Cin;
-        b_src[q] = Bt + (size_t)(n & 127) * K + slot * 8;
+        b_src[q] = Bt + (size_t)(n & 127) * K + slot * 8 + cs0 * 64;
     }
     auto stageA = [&](int cs, int buf) {
         char* dst = As + buf * A_BYTES + wid * 1024;
@@ -342,6 +352,70 @@ bank256_kernel(Bank256Args a) {
     // tile) and, per register quad q, 4 consecutive channels 8q + 4lh + {0..3}: 8-byte LDS writes.
     constexpr int EP = 528;                            // LDS row pitch of the [256][256] bf16 tile
     __syncthreads();                                   // all fragment reads retired; no load in flight
+    if (a.ksplit > 1) {
+        // ---------------- split K: the workgroups of a row tile take a ticket as they finish.  Every one but the last
+        // publishes its accumulators (register order: one wave instruction = 1 KB) with write-through stores, drains
+        // them, and signals; the last polls that word, acquires, adds the slab(s) and runs the epilogue.  Writers wait
+        // for nobody, so the exchange cannot deadlock whatever the residency; with two splits the sum a + b does not
+        // depend on who was last (cdna_hip_programming.md Guideline 16, form R1).
+        typedef __attribute__((address_space(1))) unsigned gu32;
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        gu32* const tk = (gu32*)(uintptr_t)(a.tick + 2 * rt);
+        int* const tsh = reinterpret_cast<int*>(smem);
+        if (tid == 0) tsh[0] = (int)__hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const int ticket = __builtin_amdgcn_readfirstlane(tsh[0]);
+        const int voff = (wid * 32 * 64 + lane) * 16;              // + ((i*2 + c)*4 + q) * 1024
+        float* const slab0 = a.ws + (size_t)rt * (a.ksplit - 1) * 65536;
+        if (ticket < a.ksplit - 1) {
+            const uintptr_t base = (uintptr_t)(slab0 + (size_t)ticket * 65536);
+            // (wave-uniform by construction; readfirstlane makes that provable.  It returns int: the halves go through
+            // unsigned, or the low one sign-extends into the high one)
+            const unsigned b_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)base);
+            const unsigned b_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(base >> 32));
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((uintptr_t)b_hi << 32) | (uintptr_t)b_lo), 0, 262144, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = {acc[i][c][4 * q], acc[i][c][4 * q + 1], acc[i][c][4 * q + 2], acc[i][c][4 * q + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs,
+                                                               voff + ((i * 2 + c) * 4 + q) * 1024, 0, 16);     // aux 16 = sc1
+                    }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // EVERY storing wave drains
+            __syncthreads();
+            if (tid == 0) __hip_atomic_fetch_add(tk + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        if (tid == 0) {
+            // bounded: the writers of this row tile hold their tickets already and wait for nothing
+            for (unsigned spins = 0; spins < (1u << 21); ++spins) {
+                if (__hip_atomic_load(tk + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(a.ksplit - 1)) break;
+                __builtin_amdgcn_s_sleep(16);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+        for (int sl = 0; sl < a.ksplit - 1; ++sl) {
+            const __attribute__((address_space(1))) char* sp =
+                (const __attribute__((address_space(1))) char*)(uintptr_t)(slab0 + (size_t)sl * 65536) + voff;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(sp + ((i * 2 + c) * 4 + q) * 1024);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][c][4 * q + e] += v[e];
+                    }
+        }
+        __syncthreads();                               // tsh[0] was read by every wave before the tile is written over it
+    }
     {
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -398,6 +472,21 @@ bank256_kernel(Bank256Args a) {
 
 }  // namespace
 
+int vc_bank256_ksplit(int M, int nslab) {
+    // Two workgroups per row tile while that still fits ONE round of the 256 CUs (a third would open a second round, and
+    // with more than two the sum would depend on the arrival order).
+    const int ntm = (M + BM - 1) / BM;
+    return (2 * ntm <= 256 && nslab >= 8) ? 2 : 1;
+}
+
+static size_t tick_bytes(int ntm) { return ((size_t)ntm * 8 + 255) & ~(size_t)255; }
+
+size_t vc_bank256_ws_bytes(int M, int ksplit) {
+    if (ksplit <= 1) return 0;
+    const int ntm = (M + BM - 1) / BM;
+    return tick_bytes(ntm) + (size_t)ntm * (ksplit - 1) * 262144;
+}
+
 int vc_launch_bank256(const Bank256Args& a, hipStream_t st) {
     static bool attr_done = false;
     if (!attr_done) {
@@ -408,6 +497,17 @@ int vc_launch_bank256(const Bank256Args& a, hipStream_t st) {
     const int stride = a.pool ? BM - 1 : BM;
     const int ntm = (a.M + stride - 1) / stride;
     Bank256Args b = a;
+    if (a.ksplit > 1) {
+        // [tickets | slabs] in the caller's workspace; the polled words are zeroed before EVERY launch
+        VC_REQUIRE(a.n_pairs == 1 && !a.pool && a.tick && (reinterpret_cast<uintptr_t>(a.tick) & 255) == 0,
+                   "split K: one pair, no pooled output, 256-byte aligned workspace");
+        b.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(a.tick) + tick_bytes(ntm));
+        b.xcd_tiles = 0;
+        VC_HIP_CHECK(hipMemsetAsync(a.tick, 0, tick_bytes(ntm), st));
+        hipLaunchKernelGGL(bank256_kernel, dim3((unsigned)(8 * a.ksplit * ((ntm + 7) / 8))), dim3(NT), LDS_BYTES, st, b);
+        VC_HIP_CHECK(hipGetLastError());
+        return VC_OK;
+    }
     const int xcd_mode = vc::opt(vc::OPT_BANK256_XCD);     // 0 plain grid, 1 whole pairs per XCD, else (default) split pairs
     b.xcd_tiles = (a.n_pairs >= 8 && a.n_pairs <= 16 && ntm < 32000 && xcd_mode != 0) ? ntm : 0;
     if (b.xcd_tiles > 0) {

@@ -36,6 +36,7 @@ enum Option {
     OPT_CONV256_MINK,     // shortest K that takes conv256_kernel (default 384)
     OPT_CONV256_WM,       // 2: keep 128-row blocks for 128-column launches (default: 256 rows from 2,048 rows up)
     OPT_PROJ256,          // 0: 256-channel long-K projection on conv256_kernel instead of the bank tiles
+    OPT_PROJ256_SPLIT,    // 0: never split that projection's K over two workgroups per row tile
     OPT_WGRAD_XCD,        // 0: weight-gradient tiles dealt round-robin instead of group-per-XCD
     OPT_GRU_MFMA,         // 0: VALU recurrence always, 1: MFMA recurrence always (default: from 32 sequences up)
     OPT_PRENET_LDS,       // 0: every wave of prenet_chain streams the weights itself (default: shared through LDS)

@@ -861,6 +861,7 @@ int launch_bank256(const vc_gemm_desc* d, hipStream_t st) {
     b.epi_scale = d->d_epi_scale; b.epi_shift = d->d_epi_shift; b.act = d->act;
     b.C = d->d_C; b.ldc = d->ldc; b.n_pairs = d->n_groups / 2;
     b.pool = d->epi_pool != 0;
+    b.ksplit = 1; b.ws = nullptr; b.tick = nullptr;
     for (int g = 0; g < d->n_groups; g += 2) {
         Bank256Pair& p = b.p[g / 2];
         p.Bt0 = d->groups[g].d_Bt; p.Bt1 = d->groups[g + 1].d_Bt;
@@ -905,9 +906,22 @@ bool proj256_ok(const vc_gemm_desc* d) {
     return true;
 }
 
+// Split of that projection's K over two workgroups per row tile (vc_bank256.hip, "split K"): 100 row tiles at 64 windows
+// leave 156 CUs idle when the launch has the chip to itself; two halves of K per tile fill 200.
+int proj256_ksplit(const vc_gemm_desc* d) {
+    if (vc::opt(vc::OPT_PROJ256_SPLIT) == 0) return 1;
+    return vc_bank256_ksplit(d->M, d->Cin / 64);
+}
+
 int launch_proj256(const vc_gemm_desc* d, hipStream_t st) {
     Bank256Args b;
     const vc_gemm_group& g = d->groups[0];
+    b.ksplit = 1; b.ws = nullptr; b.tick = nullptr;
+    if (const int ks = proj256_ksplit(d); ks > 1 && d->d_workspace && (reinterpret_cast<uintptr_t>(d->d_workspace) & 255) == 0 &&
+        d->workspace_bytes >= vc_bank256_ws_bytes(d->M, ks)) {
+        b.ksplit = ks;
+        b.tick = static_cast<unsigned*>(d->d_workspace);
+    }
     b.X = d->d_X; b.M = d->M; b.T = d->T; b.Cin = d->Cin; b.ldx = d->ldx;
     b.epi_scale = d->d_epi_scale; b.epi_shift = d->d_epi_shift; b.act = d->act;
     b.C = d->d_C; b.ldc = d->ldc; b.n_pairs = 1; b.pool = 0; b.dbg = 0;
@@ -1007,6 +1021,12 @@ extern "C" int vc_conv_gemm(const vc_gemm_desc* d, void* stream) {
                    "epi_pool needs act = ReLU and a launch vc_conv_gemm_epi_pool_supported() accepts");
     hipStream_t st = static_cast<hipStream_t>(stream);
     return d->dtype == VC_F32 ? launch<float>(d, ka, st) : launch<__bf16>(d, ka, st);
+}
+
+extern "C" size_t vc_conv_gemm_workspace_bytes(const vc_gemm_desc* d) {
+    if (d == nullptr || d->d_X == nullptr || d->n_groups < 1 || d->n_groups > VC_GEMM_MAX_GROUPS) return 0;
+    if (d->sum_groups || d->dtype != VC_BF16 || !proj256_ok(d)) return 0;
+    return vc_bank256_ws_bytes(d->M, proj256_ksplit(d));
 }
 
 extern "C" int vc_conv_gemm_epi_pool_supported(const vc_gemm_desc* d) {

@@ -87,25 +87,47 @@ affine_act_kernel(const float* X, const float* scale, const float* shift, int re
 //   mode 1: dBN = G * [bn(X) > 0]                                            (relu)
 //   mode 2: G is w.r.t. the max-pooled relu output P[t] = max(A[t], A[t+1]) (last frame: A[t]):
 //           dA[t] = G[t]*[t==T-1 or A[t] >= A[t+1]] + G[t-1]*[t>0 and A[t] > A[t-1]],  dBN = dA*[A>0]
+// The routing decisions of modes 1 / 2 for element (row, c): bit 0: bn(X) > 0 (relu passes), bit 1: the element
+// takes G[t] (it is the pool winner of its own frame), bit 2: it takes G[t-1] (winner of the previous frame's pool).
+// bn_upstream and vc_bn_post_routing (the export the parity tests hand to the oracle) both go through this.
+__device__ __forceinline__ int bn_route(const float* X, int ld, size_t i, int t, int T, float sc, float sh) {
+    const float a = fmaxf(X[i] * sc + sh, 0.0f);
+    if (!(a > 0.0f)) return 0;
+    int bits = 1;
+    if (t == T - 1) bits |= 2;
+    else {
+        const float an = fmaxf(X[i + ld] * sc + sh, 0.0f);
+        if (a >= an) bits |= 2;
+    }
+    if (t > 0) {
+        const float ap = fmaxf(X[i - ld] * sc + sh, 0.0f);
+        if (a > ap) bits |= 4;
+    }
+    return bits;
+}
+
 __device__ __forceinline__ float bn_upstream(const float* G, const float* X, int ld, size_t row, int c, int t, int T,
                                              float sc, float sh, int mode) {
     const size_t i = row * ld + c;
     if (mode == 0) return G[i];
-    const float a = fmaxf(X[i] * sc + sh, 0.0f);
-    if (mode == 1) return a > 0.0f ? G[i] : 0.0f;
+    if (mode == 1) return fmaxf(X[i] * sc + sh, 0.0f) > 0.0f ? G[i] : 0.0f;
+    const int bits = bn_route(X, ld, i, t, T, sc, sh);
     float g = 0.0f;
-    if (a > 0.0f) {
-        if (t == T - 1) g += G[i];
-        else {
-            const float an = fmaxf(X[i + ld] * sc + sh, 0.0f);
-            if (a >= an) g += G[i];
-        }
-        if (t > 0) {
-            const float ap = fmaxf(X[i - ld] * sc + sh, 0.0f);
-            if (a > ap) g += G[i - ld];
-        }
-    }
+    if (bits & 2) g += G[i];
+    if (bits & 4) g += G[i - ld];
     return g;
+}
+
+__global__ void __launch_bounds__(TB)
+bn_routing_kernel(const float* X, int M, int C, int ld, int T, const float* scale, const float* shift, unsigned char* out) {
+    const size_t n = (size_t)M * C;
+    size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * TB;
+    for (; i < n; i += stride) {
+        const size_t r = i / C;
+        const int c = (int)(i - r * C);
+        out[i] = (unsigned char)bn_route(X, ld, r * ld + c, (int)(r % T), T, scale[c], shift[c]);
+    }
 }
 
 // partial column sums of dBN and dBN * xhat
@@ -1116,6 +1138,16 @@ int vc_bn_backward(const float* d_G, const float* d_X, int32_t M, int32_t C, int
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + TB - 1) / TB), dim3(TB), 0, st, d_workspace, nblk, C, d_dbeta, d_dgamma);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks((size_t)M * C)), dim3(TB), 0, st, d_G, d_X, M, C, ld, T, d_gamma,
                        d_scale, d_shift, d_mean, d_rstd, d_dbeta, d_dgamma, mode, d_dX);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_bn_post_routing(const float* d_X, int32_t M, int32_t C, int32_t ld, int32_t T, const float* d_scale,
+                       const float* d_shift, uint8_t* d_bits, void* stream) {
+    VC_REQUIRE(d_X && d_scale && d_shift && d_bits, "NULL argument");
+    VC_REQUIRE(M > 0 && C > 0 && ld >= C && T > 0 && M % T == 0, "bad shape");
+    hipLaunchKernelGGL(bn_routing_kernel, dim3(nblocks((size_t)M * C)), dim3(TB), 0, static_cast<hipStream_t>(stream), d_X,
+                       M, C, ld, T, d_scale, d_shift, d_bits);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }

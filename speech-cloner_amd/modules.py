@@ -237,6 +237,13 @@ def gemm_desc(X, M, T, Cin, ldx, N, groups, Cout, ldc, vc_dtype, mode=_vc.GEMM_P
 def gemm_launch(X, M, T, Cin, ldx, N, groups, Cout, ldc, vc_dtype, **kw):
     """Fill a vc_gemm_desc (see gemm_desc) and launch vc_conv_gemm on the current stream."""
     d = gemm_desc(X, M, T, Cin, ldx, N, groups, Cout, ldc, vc_dtype, **kw)
+    if vc_dtype == _vc.VC_BF16 and len(groups) == 1 and N == 256:
+        # the one launch shape that can split K over workgroups (include/vc_hip.h, vc_gemm_desc.d_workspace): scratch from
+        # the caching allocator of the current stream, private to this call
+        nbytes = _vc.lib().vc_conv_gemm_workspace_bytes(C.byref(d))
+        if nbytes:
+            ws = _torch().empty(nbytes, dtype=_torch().uint8, device=Cout.device)
+            d.d_workspace, d.workspace_bytes = ws.data_ptr(), nbytes
     _vc.check(_vc.lib().vc_conv_gemm(C.byref(d), _vc.current_stream()))
     return Cout
 

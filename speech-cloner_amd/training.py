@@ -177,6 +177,8 @@ class StageTrainer:
         self._pending = []                           # gradient buckets already being all-reduced (data parallel)
         self.overlap_allreduce = True                # False: one blocking all-reduce in apply_gradients (tests)
         self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
+        self.export_routing = False                  # True: keep every relu / max-pool decision of the step (parity tests)
+        self.routing = {}
 
     def load_slots(self, ckpt):
         """Resume Adam state from a checkpoint dict (TF slot names <opt>/<var>/Adam, /Adam_1)."""
@@ -265,6 +267,13 @@ class StageTrainer:
         gemm_launch(D2, M, T_, H, H, BANK_FILTERS, groups, Zb, CB, f32, out_f32=True)
         sb = _Ops.bn_stats(Zb, M, CB, self.w(b + '/bn/gamma'), self.w(b + '/bn/beta'),
                            self.w(b + '/bn/moving_mean'), self.w(b + '/bn/moving_variance'))
+        if self.export_routing:
+            # parity tests: the relu / pool-winner decisions the backward pass will take on this tensor, for the oracle
+            bits = torch.empty((M, CB), dtype=torch.uint8, device=dev)
+            _vc.check(_lib().vc_bn_post_routing(_p(Zb), M, CB, CB, T_, _p(sb[0]), _p(sb[1]), _p(bits), _st()))
+            self.routing[s] = {'banks': bits.view(N_, T_, CB),
+                               # vc_relu_dropout_backward passes the gradient where the stored output is > 0
+                               'prenet': ((D1 > 0).view(N_, T_, E), (D2 > 0).view(N_, T_, H)), 'highway': [None] * n_hw}
         # conv1d_1 on pool(relu(bn(Zb))) -- normalisation, relu and pool in the operand prologue
         p1 = s + '/CBHG/conv1d_1'
         Q1 = torch.empty((M, H), dtype=torch.float32, device=dev)
@@ -272,6 +281,10 @@ class StageTrainer:
                     pro_scale=sb[0], pro_shift=sb[1], pro_relu=1, pro_pool=1, out_f32=True)
         s1 = _Ops.bn_stats(Q1, M, H, self.w(p1 + '/gamma'), self.w(p1 + '/beta'), self.w(p1 + '/moving_mean'),
                            self.w(p1 + '/moving_variance'))
+        if self.export_routing:                    # vc_bn_backward mode 1: bn(Q1) > 0 (bit 0 of the same export)
+            bits = torch.empty((M, H), dtype=torch.uint8, device=dev)
+            _vc.check(_lib().vc_bn_post_routing(_p(Q1), M, H, H, T_, _p(s1[0]), _p(s1[1]), _p(bits), _st()))
+            self.routing[s]['conv1d_1'] = (bits & 1).bool().view(N_, T_, H)
         p2 = s + '/CBHG/conv1d_2'
         Q2 = torch.empty((M, H), dtype=torch.float32, device=dev)
         gemm_launch(Q1, M, T_, H, H, H, [(modules._prep_conv(st, p2, 3, H, H), 3 * H, 3, 1, 0)], Q2, H, f32,
@@ -395,6 +408,8 @@ class StageTrainer:
             Xi = sv['Ys'][i]
             pre = torch.empty((M, NP), dtype=torch.float32, device=dev)
             gemm_launch(Xi, M, T_, H, H, NP, [(bt, H, 1, 0, 0)], pre, NP, f32, epi_shift=bias, out_f32=True)
+            if self.export_routing and H % 32 == 0:       # vc_highway_backward: dense1's relu passes where its re-computed
+                self.routing[s]['highway'][i] = (pre.view(M, H // 32, 2, 32)[:, :, 0, :] > 0).reshape(N_, T_, H)   # pre-activation > 0
             dp = torch.empty((M, NP), dtype=torch.float32, device=dev)
             dXd = torch.empty((M, H), dtype=torch.float32, device=dev)
             _vc.check(_lib().vc_highway_backward(_p(pre), NP, _p(Xi), _p(dYc), M, H, _p(dp), _p(dXd), _st()))
@@ -551,14 +566,14 @@ class StageTrainer:
             self._pending.append((lo, hi, torch.distributed.all_reduce(self.grad[lo:hi], op=torch.distributed.ReduceOp.SUM,
                                                                         async_op=True)))
 
-    def apply_gradients(self, world=1):
-        """All-reduce (data parallel), Adam, bookkeeping.  decoder.py:236-246 / encoder.py:171-181.  Buckets that
-        forward_backward already put on the wire are waited for; whatever they do not cover is summed here."""
+    def _complete_exchange(self):
+        """Data parallel: after this every element of the gradient arena has been summed over the ranks exactly once
+        and the current stream may read it.  Buckets forward_backward already put on the wire are waited for; every
+        stretch of [0, total) they do not cover is all-reduced here (for the encoder trainer, which starts no bucket,
+        that is the whole arena in one call).  Whether there is anything to exchange is the process group's business,
+        not the caller's: ``world`` in apply_gradients only scales Adam."""
         torch = _torch()
-        c = self.cfg
         self._join_side()                             # weight gradients still running on the side stream
-        # whether there is anything to exchange is the process group's business, not the caller's argument: buckets
-        # already on the wire are always waited for; ``world`` only scales Adam (1 / world)
         dist_world = torch.distributed.get_world_size() if (torch.distributed.is_available() and
                                                              torch.distributed.is_initialized()) else 1
         if dist_world > 1 or self._pending:
@@ -571,6 +586,13 @@ class StageTrainer:
                 pos = max(pos, hi)
             for _, _, work in pending:
                 work.wait()
+
+    def apply_gradients(self, world=1):
+        """All-reduce (data parallel), Adam, bookkeeping.  decoder.py:236-246 / encoder.py:171-181.  Buckets that
+        forward_backward already put on the wire are waited for; whatever they do not cover is summed here."""
+        torch = _torch()
+        c = self.cfg
+        self._complete_exchange()
         self.step_count += 1
         t = self.step_count
         lr = float(self.dec.opt_state[self.opt_scope + '/learning_rate'])

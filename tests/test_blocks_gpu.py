@@ -527,8 +527,10 @@ def test_wide_projection_on_the_bank_tiles(N, T, cin, k):
                 st.assign(n, rng.uniform(-0.3, 0.3, tuple(v.shape)).astype(np.float32))
         y_ref = modules.conv1d(xd, **kw)
         _vc.set_option('proj256', -1)
+        _vc.set_option('proj256_split', 0)               # one workgroup per row tile: the same summation order
         poison_gpu_state()
         y = modules.conv1d(xd, **kw)
+        _vc.set_option('proj256_split', -1)
     torch.cuda.synchronize()
     assert not torch.isnan(y.float()).any()
     assert torch.equal(y, y_ref)
@@ -537,6 +539,71 @@ def test_wide_projection_on_the_bank_tiles(N, T, cin, k):
     cast = lambda t: t.bfloat16().double()
     ref = torch.relu(mo.bn(mo.conv1d(cast(x), cast(st.vars['p/c/conv1d/kernel'].cpu())), w, 'p/c'))
     _close(y, ref, TOL['bfloat16'], 'proj256 cin=%d k=%d' % (cin, k))
+
+
+@pytest.mark.parametrize('N,T,cin,k', [(64, 400, 4096, 3), (4, 400, 4096, 3), (5, 250, 1024, 5), (3, 400, 2048, 2)])
+def test_wide_projection_with_k_split_over_two_workgroups(N, T, cin, k):
+    """The same projection with its K split over two workgroups per row tile (vc_bank256.hip "split K": the first to
+    finish publishes its float32 accumulators, the second adds them and runs the epilogue) -- what a launch with at most
+    128 row tiles uses when the caller hands it a workspace (modules.gemm_launch does).  (64, 400, 4096, 3) is decoder
+    stage 2's first projection at the benchmarked batch (/root/reference/modules.py:334-335).
+      * against the oracle at the block tolerance, and against the unsplit launch within one bf16 rounding of the
+        result (the two differ only in where the float32 sum over K is associated);
+      * deterministic: a + b does not depend on which half arrives last -- repeated launches, NaN-poisoned LDS and
+        workspace, an unrelated stream keeping CUs busy (uneven arrival), must be bit-identical;
+      * without a workspace the unsplit form runs (same result as proj256_split = 0)."""
+    import ctypes as C
+    import modules
+    from conftest import poison_gpu_state
+    rng = np.random.RandomState(cin + k + N)
+    st = _store('bfloat16')
+    x = torch.from_numpy(rng.standard_normal((N, T, cin)).astype(np.float32) * 0.5)
+    xd = modules.convert(x.cuda(), st.dtype)
+    kw = dict(filters=256, size=k, scope='c', bn_scope='c', activation_fn='relu')
+    with modules.variable_store(st), modules.variable_scope('p'):
+        modules.conv1d(xd, **kw)
+        for n, v in list(st.vars.items()):
+            if n.endswith('gamma') or n.endswith('moving_variance'):
+                st.assign(n, rng.uniform(0.5, 1.5, tuple(v.shape)).astype(np.float32))
+            elif n.endswith('beta') or n.endswith('moving_mean'):
+                st.assign(n, rng.uniform(-0.3, 0.3, tuple(v.shape)).astype(np.float32))
+        _vc.set_option('proj256_split', 0)
+        y_one = modules.conv1d(xd, **kw)
+        _vc.set_option('proj256_split', -1)
+        # the library asks for a workspace for this launch, i.e. the split form is what runs next
+        d = modules.gemm_desc(xd, N * T, T, cin, cin, 256, [(modules._prep_conv(st, 'p/c', k, cin, 256), k * cin, k, (k - 1) // 2, 0)],
+                              torch.empty((N * T, 256), dtype=torch.bfloat16, device='cuda'), 256, _vc.VC_BF16)
+        need = _vc.lib().vc_conv_gemm_workspace_bytes(C.byref(d))
+        ntm = (N * T + 255) // 256
+        assert need == ((ntm * 8 + 255) // 256) * 256 + ntm * 262144, need
+        noise_stream = torch.cuda.Stream()
+        noise_store = modules.VariableStore('bfloat16')
+        noise_x = torch.randn(8, 400, 256, device='cuda').to(torch.bfloat16)
+        ys = []
+        for rep in range(4):
+            poison_gpu_state()
+            if rep & 1:
+                with torch.cuda.stream(noise_stream), modules.variable_store(noise_store), modules.variable_scope('noise'):
+                    for _ in range(3):
+                        modules.conv1d_banks(noise_x, K=32, is_training=False)
+            ys.append(modules.conv1d(xd, **kw))
+        torch.cuda.synchronize()
+    y = ys[0]
+    assert not torch.isnan(y.float()).any()
+    for other in ys[1:]:
+        assert torch.equal(y, other)
+    # one bf16 rounding of the stored value: |a - b| <= 2^-7 max(|a|, |b|) (+ a float32-sum allowance near zero)
+    a_, b_ = y.float(), y_one.float()
+    assert bool(((a_ - b_).abs() <= 2.0 ** -7 * torch.maximum(a_.abs(), b_.abs()) + 1e-3).all())
+    assert float((a_ != b_).float().mean()) < 0.2          # and most values do not even move
+    w = {n: v.cpu().double() for n, v in st.vars.items()}
+    cast = lambda t: t.bfloat16().double()
+    sub = slice(0, min(N, 4))                            # the oracle on a few windows is enough (and seconds, not minutes)
+    ref = torch.relu(mo.bn(mo.conv1d(cast(x[sub]), cast(st.vars['p/c/conv1d/kernel'].cpu())), w, 'p/c'))
+    _close(y[sub], ref, TOL['bfloat16'], 'proj256 split cin=%d k=%d' % (cin, k))
+    if N > 4:
+        ref = torch.relu(mo.bn(mo.conv1d(cast(x[-2:]), cast(st.vars['p/c/conv1d/kernel'].cpu())), w, 'p/c'))
+        _close(y[-2:], ref, TOL['bfloat16'], 'proj256 split, last windows')
 
 
 def test_softmax_dual_output_equals_two_launches():

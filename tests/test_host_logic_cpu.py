@@ -237,3 +237,108 @@ def test_dataset_filter_and_split_logic_match_oracle():
         d.get_ds_filter({'split_d': {'split_key': 'spk_id', 'split_type': 'x', 'split_props_v': (0.1, 0.2)}})
     with pytest.raises(Exception, match='tupla de len 2'):
         d.get_ds_filter({'split_d': {'split_key': 'spk_id', 'split_type': 'trn', 'split_props_v': [0.1, 0.2]}})
+
+
+def test_oracle_given_routing_reproduces_its_own_forward():
+    """oracle/model_oracle.py: conv1d_banks(relu_on=...) / max_pool_2_same(winners=...) with the routing derived from
+    the oracle's OWN pre-activations (the rule of vc_bn_post_routing, include/vc_hip.h: relu passes a > 0; a frame
+    wins its own pool output when it is the last frame or >= its successor, the previous frame's when strictly greater
+    than its predecessor) give exactly relu + max-pool, values and gradients."""
+    import torch
+    rng = np.random.RandomState(1)
+    x = torch.from_numpy(rng.standard_normal((3, 17, 6))).requires_grad_(True)
+    a = torch.relu(x)
+    ref = mo.max_pool_2_same(a)
+    g = torch.from_numpy(rng.standard_normal(ref.shape))
+    (ref * g).sum().backward()
+    gref = x.grad.clone()
+    x.grad = None
+    ad = a.detach()
+    T = ad.shape[1]
+    nxt = torch.cat([ad[:, 1:], ad[:, -1:]], 1)
+    prv = torch.cat([ad[:, :1], ad[:, :-1]], 1)
+    t = torch.arange(T)[None, :, None]
+    on = ad > 0
+    own = on & ((t == T - 1) | (ad >= nxt))
+    prev = on & (t > 0) & (ad > prv)
+    bits = on.to(torch.uint8) | (own.to(torch.uint8) << 1) | (prev.to(torch.uint8) << 2)
+    r = mo.routing_from_bits(bits)
+    y = mo.max_pool_2_same(x * r[0], r[1:])
+    assert torch.equal(y.detach(), ref.detach())
+    (y * g).sum().backward()
+    assert torch.equal(x.grad, gref)
+
+
+def test_gradient_buckets_cover_the_arena_exactly_once(monkeypatch):
+    """Data-parallel exchange (training.py: _start_allreduce / _complete_exchange; decoder.py:236-246 analogue under
+    DP): the two overlapped buckets of the decoder trainer (stage 2 first, then stage 1) plus whatever
+    _complete_exchange sums itself must cover [0, total) of the flat gradient arena exactly once -- an element summed
+    twice or never would train replicas apart silently.  Checked for both trainers at the shipped sizes with a
+    recording stand-in for the process group (no GPU, no kernels: only the bookkeeping runs)."""
+    import torch
+    import training
+    from encoder import encoder_spec_phn
+    from decoder import decoder_specs
+    ec = json.load(open(os.path.join(HP, 'encoder_cfg_d.json')))
+    dc = json.load(open(os.path.join(HP, 'decoder_cfg_d.json')))
+    ec.update(is_training=True, device='cpu')
+    dc.update(is_training=True, device='cpu')
+    calls = []
+
+    class Work:
+        waited = 0
+
+        def wait(self):
+            Work.waited += 1
+
+    def fake_all_reduce(t, op=None, async_op=False):
+        calls.append((t.data_ptr(), t.numel(), async_op))
+        return Work() if async_op else None
+
+    monkeypatch.setattr(torch.distributed, 'is_initialized', lambda: True)
+    monkeypatch.setattr(torch.distributed, 'get_world_size', lambda *a: 2)
+    monkeypatch.setattr(torch.distributed, 'all_reduce', fake_all_reduce)
+
+    def covered(tr):
+        base = tr.grad.data_ptr()
+        spans = sorted(((p - base) // 4, (p - base) // 4 + n) for p, n, _ in calls)
+        assert spans[0][0] == 0 and spans[-1][1] == tr.total, spans
+        for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+            assert a1 == b0, 'gap or overlap between %s and %s' % ((a0, a1), (b0, b1))
+        return spans
+
+    # decoder: the two buckets forward_backward starts, in its order, then the completion
+    dec = decoder_specs(dc, None, None)
+    tr = training.DecoderTrainer(dec)
+    assert tr.total == 33186713
+    tr._start_allreduce(*tr._slice_of('decoder/step2/'))
+    tr._start_allreduce(*tr._slice_of('decoder/step1/'))
+    assert len(tr._pending) == 2 and all(c[2] for c in calls)
+    tr._complete_exchange()
+    spans = covered(tr)
+    assert len(spans) == 2 and Work.waited == 2 and tr._pending == []         # nothing left for the gap filler
+    assert spans[1][1] - spans[1][0] > spans[0][1] - spans[0][0]            # stage 2 (created last) is the larger bucket
+    # only ONE bucket went out (e.g. an exception between the stages): the completion sums the rest itself
+    calls.clear()
+    tr._start_allreduce(*tr._slice_of('decoder/step2/'))
+    tr._complete_exchange()
+    assert len(covered(tr)) == 2 and [c[2] for c in calls] == [True, False]
+    # overlap switched off: one blocking all-reduce of everything
+    calls.clear()
+    tr.overlap_allreduce = False
+    tr._start_allreduce(*tr._slice_of('decoder/step2/'))
+    tr._complete_exchange()
+    assert covered(tr) == [(0, tr.total)]
+    # a forward_backward that finds buckets nobody consumed waits for them before touching the arena
+    tr.overlap_allreduce = True
+    calls.clear()
+    Work.waited = 0
+    tr._start_allreduce(*tr._slice_of('decoder/step2/'))
+    tr._drain_pending()
+    assert Work.waited == 1 and tr._pending == []
+    # encoder: starts no bucket -> the completion is one all-reduce of the whole arena
+    calls.clear()
+    enc = encoder_spec_phn(ec, None)
+    te = training.EncoderTrainer(enc)
+    te._complete_exchange()
+    assert covered(te) == [(0, te.total)]

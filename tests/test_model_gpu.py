@@ -211,8 +211,8 @@ def test_forced_mfma_recurrence_on_small_chunks_under_stream_overlap(golden_dir)
     3-stream predict differed from the sequential pass once, with the MFMA recurrence forced onto 2-window chunks).
     DESIGN.md section 9 audits every launch of that configuration; this test IS that configuration -- MFMA
     recurrence forced for H = 128 / 256 with 2 of the 16 sequence slots used, chunks of two windows and a ragged
-    last chunk, three and four streams, NaN-poisoned LDS and allocator -- repeated, half of the repeats with an
-    unrelated stream keeping the chip busy with LDS-filling filter-bank launches (timing perturbation)."""
+    last chunk, NaN-poisoned LDS and allocator -- once on three streams, once on four with an unrelated stream
+    keeping the chip busy with LDS-filling filter-bank launches (timing perturbation)."""
     import _vc
     import modules
     from encoder import encoder_spec_phn
@@ -231,16 +231,17 @@ def test_forced_mfma_recurrence_on_small_chunks_under_stream_overlap(golden_dir)
         _vc.set_option('gru_mfma', 1)
         a = dec.predict(x, batch_size=2, n_streams=1)
         assert not any(np.isnan(v).any() for v in a)
-        for rep in range(10):
+        # the two distinct cases (a regression case, not a fault hunt: repeating it would be looking for luck)
+        for noise, n_streams in ((False, 3), (True, 4)):
             poison_gpu_state()
-            if rep & 1:
+            if noise:
                 with torch.cuda.stream(noise_stream), modules.variable_store(noise_store), modules.variable_scope('noise'):
                     for _ in range(6):
                         modules.conv1d_banks(noise_x, K=32, is_training=False)
-            b = dec.predict(x, batch_size=2, n_streams=3 + (rep % 3 == 2))
+            b = dec.predict(x, batch_size=2, n_streams=n_streams)
             for name, u_, v_ in zip(a._fields, a, b):
-                assert np.array_equal(u_, v_), 'repeat %d: %s differs from the sequential pass (max %g)' % (
-                    rep, name, np.abs(u_ - v_).max())
+                assert np.array_equal(u_, v_), 'noise %s, %d streams: %s differs from the sequential pass (max %g)' % (
+                    noise, n_streams, name, np.abs(u_ - v_).max())
         torch.cuda.synchronize()
     finally:
         _vc.set_option('gru_mfma', -1)
