@@ -58,6 +58,7 @@ const char* vc_target_arch(void);
  *   "proj256_split"  0 = never split that projection's K over two workgroups per row tile (see d_workspace)
  *   "wgrad_xcd"      0 = weight-gradient tiles dealt round-robin to the XCDs
  *   "gru_mfma"       0 = VALU recurrence always, 1 = MFMA recurrence always (default: from 32 sequences up)
+ *   "gru_mfma4"      1 = the four-wave MFMA recurrence with all weights in registers (bit-identical, measured slower)
  *   "prenet_lds"     0 = every wave of the fused prenet streams the weights from L2 itself (default: one stream per
  *                    block, shared through LDS)
  *   "gru_train_resident" 0 = the float32 training recurrences stream all their weights from L2 every step (default:

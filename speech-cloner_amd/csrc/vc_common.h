@@ -39,6 +39,7 @@ enum Option {
     OPT_PROJ256_SPLIT,    // 0: never split that projection's K over two workgroups per row tile
     OPT_WGRAD_XCD,        // 0: weight-gradient tiles dealt round-robin instead of group-per-XCD
     OPT_GRU_MFMA,         // 0: VALU recurrence always, 1: MFMA recurrence always (default: from 32 sequences up)
+    OPT_GRU_MFMA4,        // 1: the four-wave, all-weights-in-registers MFMA recurrence (measured slower; default: eight waves)
     OPT_PRENET_LDS,       // 0: every wave of prenet_chain streams the weights itself (default: shared through LDS)
     OPT_GRU_TRAIN_RESIDENT,   // 0: the float32 training recurrences stream all their weights from L2 every step
     OPT_CBHG_FRONT_MI,    // 4: 128-row blocks in cbhg_small_kernel (default 2)

@@ -576,6 +576,262 @@ int launch_mfma(const GruArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// MFMA recurrence, four-wave form (bf16, H = 128 / 256): the same 16 sequences per workgroup, but ONE wave per SIMD with the
+// SIMD's whole register file (512 registers), so that
+//   * ALL recurrent weights stay on chip in registers for the T steps except the second half of the candidate tiles'
+//     k-steps at H = 256 (LDS): the r / u fragments are named as ACCUMULATOR-file operands of hand-placed matrix
+//     instructions (hipcc keeps builtin MFMA operands in the 256 architectural registers and copied 214 registers per
+//     step out of the accumulator half when left to itself),
+//   * a wave owns 64 (H = 256) / 32 (H = 128) hidden units = 4 / 2 independent accumulator chains per gate, enough to
+//     keep the matrix pipe fed from ONE gate at a time: r's products are issued first, u's behind them with r's sigmoids
+//     dealt into the gaps between them (a 16x16x32 product holds the vector issue for 8 of its 16 cycles); u's sigmoids
+//     sit between the candidate's products,
+//   * the two barriers per step are 4-wave, LDS-only barriers (~100 cycles; in the eight-wave form each SIMD's two waves
+//     serialise on the matrix pipe, which shows as ~600 cycles of "barrier" per phase: tools/gru_phase_stamps.py).
+// MEASURED, NOT SHIPPED AS THE DEFAULT (vc_set_option("gru_mfma4", 1) selects it; bit-identical results): 2.79 us per
+// step against the eight-wave kernel's 2.01 at H = 256, 1.07 against 1.03 at H = 128 (profiles/r03/ab_gru_mfma4.log,
+// phase stamps beside it).  The step is bound by VECTOR issue, not by where the weights live: 96 transcendentals and
+// ~250 other vector instructions per lane and step are ~1,900 issue cycles, of which one wave per SIMD can hide only what
+// fits into the 8 free cycles beside each 16-cycle product, while two waves per SIMD overlap one wave's gate arithmetic
+// with the other's products for free.  Also measured on the way: prefetching the input projections by LDS-direct loads
+// into a ring costs ~200 cycles of issue PER 1-KB piece beside the products (12 pieces = 2,373 of 6,959 cycles per step).
+template <int H> struct Mf4Geom {
+    static constexpr int NW = 4, UW = H / NW, TPW = UW / 16, KSN = H / 32;
+    static constexpr int NF_G = 2 * TPW * KSN, NF_C = TPW * KSN, NF = NF_G + NF_C;
+    static constexpr int PITCH = H + 8;
+    static constexpr int KL = (H >= 256) ? 4 : 0;            // k-steps of every candidate tile whose fragments sit in LDS
+    static constexpr int KR = KSN - KL;
+    static constexpr size_t LDS = 2 * 16 * (size_t)PITCH * 2 + (size_t)NW * TPW * KL * 64 * 16;
+};
+
+template <int H>
+__global__ void __launch_bounds__(256)
+gru_mfma4_pack_kernel(const __bf16* W0, const __bf16* W1, __bf16* packed) {
+    typedef Mf4Geom<H> G;
+    const int total = 2 * G::NW * G::NF * 64 * 8;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        int r = idx;
+        const int j = r & 7; r >>= 3;
+        const int lane = r & 63; r >>= 6;
+        const int f = r % G::NF; r /= G::NF;
+        const int wave = r % G::NW;
+        const int dir = r / G::NW;
+        int g, rem;
+        if (f < G::NF_G) { g = f / (G::TPW * G::KSN); rem = f % (G::TPW * G::KSN); }
+        else { g = 2; rem = f - G::NF_G; }
+        const int tl = rem / G::KSN, ks = rem % G::KSN;
+        const int k = ks * 32 + 8 * (lane >> 4) + j;
+        const int col = g * H + wave * G::UW + tl * 16 + (lane & 15);
+        const __bf16* W = dir ? W1 : W0;
+        packed[idx] = W[(size_t)k * 3 * H + col];
+    }
+}
+
+template <int H>
+__global__ void __launch_bounds__(256, 1)
+gru_mfma4_kernel(GruArgs a, const __bf16* packed) {
+    typedef Mf4Geom<H> G;
+    constexpr int TPW = G::TPW, KSN = G::KSN, PITCH = G::PITCH, UW = G::UW, KL = G::KL, KR = G::KR;
+    typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* hb = reinterpret_cast<__bf16*>(smem);                 // [16][PITCH]
+    __bf16* rhb = hb + 16 * PITCH;                                // [16][PITCH]
+    bf16x8v* candL = reinterpret_cast<bf16x8v*>(rhb + 16 * PITCH);   // [NW][TPW][KL][64]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int dir = blockIdx.y, seq0 = blockIdx.x * 16;
+    const int n = lane & 15, q = lane >> 4;
+    const int seq = min(seq0 + n, a.n_seq - 1);
+    const bool seq_ok = (seq0 + n) < a.n_seq;
+    const bf16x8v* pk = reinterpret_cast<const bf16x8v*>(packed) + ((size_t)(dir * G::NW + wave) * G::NF) * 64 + lane;
+
+    bf16x8v wr[TPW][KSN], wu[TPW][KSN], wc[TPW][KR];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl)
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) {
+            wr[tl][ks] = pk[(size_t)((0 * TPW + tl) * KSN + ks) * 64];
+            wu[tl][ks] = pk[(size_t)((1 * TPW + tl) * KSN + ks) * 64];
+            const bf16x8v c = pk[(size_t)(G::NF_G + tl * KSN + ks) * 64];
+            if (ks < KR) wc[tl][ks < KR ? ks : 0] = c;
+            else candL[((wave * TPW + tl) * KL + (ks - KR)) * 64 + lane] = c;
+        }
+    for (int i = tid; i < 2 * 16 * PITCH; i += 256) hb[i] = (__bf16)0.0f;       // hb and rhb are adjacent
+    float hreg[TPW][4];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hreg[tl][e] = 0.0f;
+
+    const int H3 = 3 * H;
+    const size_t xrow = 6 * (size_t)H;
+    const int ucol = wave * UW + q * 4;                          // first of this lane's 4 units in tile 0
+    const float* xbase = a.xproj + (size_t)seq * a.T * xrow + (size_t)dir * H3 + ucol;
+    int t = dir ? a.T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    f32x4m xr[TPW], xu[TPW], xc[TPW];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) {
+        const float* xp = xbase + (size_t)t * xrow + tl * 16;
+        xr[tl] = *reinterpret_cast<const f32x4m*>(xp);
+        xu[tl] = *reinterpret_cast<const f32x4m*>(xp + H);
+        xc[tl] = *reinterpret_cast<const f32x4m*>(xp + 2 * H);
+    }
+    __syncthreads();
+
+    const __bf16* hrow = hb + n * PITCH + 8 * q;                 // B-fragment source of this lane
+    const __bf16* rrow = rhb + n * PITCH + 8 * q;
+    // LDS-only barrier: every wave's LDS writes have completed (lgkmcnt); the loads of the next step's input projections
+    // and this step's output stores stay in flight across it (__syncthreads() would drain them: vmcnt(0))
+#define GRU4_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    // One product with the weight fragment as an accumulator-file ("a") or architectural ("v") operand.  hipcc pads
+    // nothing around asm: the leading s_nop covers a compiler-made copy of an operand right in front of the statement;
+    // a chain's result is first read by VALU code at least four matrix instructions later (an XDL result of this shape
+    // needs about a dozen wait states before a VALU read), which the empty "+v" statements below pin.
+#define GRU4_MFMA(acc, w, b, in_acc)                                                                                   \
+    do {                                                                                                               \
+        if (in_acc) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "a"(w), "v"(b));   \
+        else asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(b));         \
+    } while (0)
+#ifdef VC_ABLATE
+    const bool stamp = blockIdx.x == 0 && blockIdx.y == 0 && tid == 0;
+    unsigned long long acc_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = __builtin_amdgcn_s_memtime();
+#endif
+    for (int step = 0; step < a.T; ++step, t += dt) {
+        const float* xn = xbase + (size_t)(step + 1 < a.T ? t + dt : t) * xrow;
+        // ---- phase 1: r, then u with r's sigmoids in its gaps
+        bf16x8v bfr[KSN];
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8v*>(hrow + ks * 32);
+        f32x4m ar[TPW], au[TPW];
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+            ar[tl] = xr[tl];
+            au[tl] = xu[tl];
+            xr[tl] = *reinterpret_cast<const f32x4m*>(xn + tl * 16);          // next step's, in place
+            xu[tl] = *reinterpret_cast<const f32x4m*>(xn + tl * 16 + H);
+        }
+        GRU_T(0);                                                    // requests of the next step's projections issued
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+            for (int tl = 0; tl < TPW; ++tl) GRU4_MFMA(ar[tl], wr[tl][ks], bfr[ks], true);
+        float rhf[TPW][4];
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) {
+#pragma unroll
+            for (int tl = 0; tl < TPW; ++tl) GRU4_MFMA(au[tl], wu[tl][ks], bfr[ks], !(H >= 256 && tl == TPW - 1 && ks >= KSN - 4));
+            // r's sigmoids, dealt over u's k-steps 1 .. KSN - 1 (r's last product lies >= TPW matrix instructions back).
+            // The empty statements pin each share between two groups of products: its inputs are opaque until the group
+            // before it has been issued, its results are demanded before the group after it.
+            constexpr int PER = (TPW * 4 + KSN - 2) / (KSN - 1);         // values per gap
+            if (ks >= 1) {
+#pragma unroll
+                for (int v = (ks - 1) * PER; v < ks * PER && v < TPW * 4; ++v) {
+                    const int tl = v >> 2, e = v & 3;
+                    if (e == 0 || v == (ks - 1) * PER) asm volatile("" : "+v"(ar[tl]));
+                    rhf[tl][e] = fast_sigmoid(ar[tl][e]) * hreg[tl][e];
+                    asm volatile("" : "+v"(rhf[tl][e]));
+                }
+            }
+        }
+        GRU_T(1);                                                    // fragments read, r and u products issued, r's sigmoids
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+            bf16x4v o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)rhf[tl][e];
+            *reinterpret_cast<bf16x4v*>(rhb + n * PITCH + ucol + tl * 16) = o;
+        }
+        GRU_T(2);                                                    // r*h stored
+        GRU4_BARRIER();                                              // barrier A: r*h complete
+        GRU_T(3);
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) asm volatile("" : "+v"(au[tl]));      // u's readers: behind the barrier
+        // ---- phase 2: candidate (u's sigmoids between its products), state update
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8v*>(rrow + ks * 32);
+        f32x4m ac[TPW];
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+            ac[tl] = xc[tl];
+            xc[tl] = *reinterpret_cast<const f32x4m*>(xn + tl * 16 + 2 * H);
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+            for (int tl = 0; tl < TPW; ++tl) {
+                const bf16x8v w = ks < KR ? wc[tl][ks < KR ? ks : 0] : candL[((wave * TPW + tl) * KL + (ks < KR ? 0 : ks - KR)) * 64 + lane];
+                ac[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, bfr[ks], ac[tl], 0, 0, 0);
+            }
+        float uu[TPW][4];
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) uu[tl][e] = fast_sigmoid(au[tl][e]);
+        bf16x4v ob[TPW];
+        f32x4m hv[TPW];
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float c = fast_tanh(ac[tl][e]);
+                const float hn = uu[tl][e] * hreg[tl][e] + (1.0f - uu[tl][e]) * c;
+                hreg[tl][e] = hn;
+                hv[tl][e] = hn;
+                ob[tl][e] = (__bf16)hn;
+            }
+            *reinterpret_cast<bf16x4v*>(hb + n * PITCH + ucol + tl * 16) = ob[tl];
+        }
+        GRU_T(4);                                                    // candidate products, u's sigmoids, tanh, update, h stored
+        if (seq_ok) {
+            if (a.out_bf16) {
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl)
+                    *reinterpret_cast<bf16x4v*>(reinterpret_cast<__bf16*>(a.out) + ((size_t)seq * a.T + t) * 2 * H + (size_t)dir * H + ucol + tl * 16) = ob[tl];
+            } else {
+#pragma unroll
+                for (int tl = 0; tl < TPW; ++tl)
+                    *reinterpret_cast<f32x4m*>(reinterpret_cast<float*>(a.out) + ((size_t)seq * a.T + t) * 2 * H + (size_t)dir * H + ucol + tl * 16) = hv[tl];
+            }
+        }
+        GRU_T(5);                                                    // output stores issued
+        GRU4_BARRIER();                                              // barrier B: h complete
+        GRU_T(6);
+    }
+#undef GRU4_MFMA
+#undef GRU4_BARRIER
+#ifdef VC_ABLATE
+    if (stamp) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) g_gru_stamps[i] = acc_t[i];
+    }
+#endif
+}
+
+template <int H>
+int launch_mfma4(const GruArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    typedef Mf4Geom<H> G;
+    const size_t need = 2 * (size_t)3 * H * H * sizeof(__bf16);
+    if (ws == nullptr || ws_bytes < need)
+        return vc::set_error(VC_ERR_WORKSPACE, "vc_gru_bidir: workspace too small (%zu < %zu)", ws_bytes, need);
+    __bf16* packed = static_cast<__bf16*>(ws);
+    hipLaunchKernelGGL((gru_mfma4_pack_kernel<H>), dim3(256), dim3(256), 0, st, static_cast<const __bf16*>(a.Wh[0]),
+                       static_cast<const __bf16*>(a.Wh[1]), packed);
+    static bool attr_done = false;
+    if (!attr_done) {
+        VC_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(gru_mfma4_kernel<H>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::LDS));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gru_mfma4_kernel<H>), dim3((a.n_seq + 15) / 16, 2), dim3(256), G::LDS, st, a,
+                       static_cast<const __bf16*>(packed));
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Single-wave recurrence for small H (the encoder: H = 40): one 64-lane wave per (window,
 // direction), no LDS and no barriers.  Lane j owns hidden unit j: its three weight columns
 // (r_j, u_j, c_j: 3H f32 registers) and h_j.  h is broadcast to the wave one element at a time
@@ -733,10 +989,13 @@ int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw,
     // windows); small batches keep the low-latency form.  vc_set_option("gru_mfma", 0 / 1) forces either.
     const int gm = vc::opt(vc::OPT_GRU_MFMA);
     const bool use_valu = gm >= 0 ? (gm != 1) : (n_seq < 32);
+    const bool four = vc::opt(vc::OPT_GRU_MFMA4) == 1;        // 1: the four-wave form (measured slower: see its comment); default: eight waves
     if (w_dtype == VC_BF16 && H == 256) return use_valu ? launch_resident<256, __bf16, 512>(a, d_workspace, workspace_bytes, st)
-                                                        : launch_mfma<256>(a, d_workspace, workspace_bytes, st);
+                                               : four ? launch_mfma4<256>(a, d_workspace, workspace_bytes, st)
+                                                      : launch_mfma<256>(a, d_workspace, workspace_bytes, st);
     if (w_dtype == VC_BF16 && H == 128) return use_valu ? launch_resident<128, __bf16, 256>(a, d_workspace, workspace_bytes, st)
-                                                        : launch_mfma<128>(a, d_workspace, workspace_bytes, st);
+                                               : four ? launch_mfma4<128>(a, d_workspace, workspace_bytes, st)
+                                                      : launch_mfma<128>(a, d_workspace, workspace_bytes, st);
     // (H = 128 runs 256 threads: four fat waves beat sixteen thin ones, the step is barrier-bound)
     if (w_dtype == VC_F32 && H == 128) return launch_resident<128, float, 1024>(a, d_workspace, workspace_bytes, st);
     if (H == 40) {                                      // the shipped encoder (hp/encoder_cfg_d.json)

@@ -376,19 +376,33 @@ def test_highway_chain_single_launch(N, T, H, L):
 @pytest.mark.parametrize('H,T,N', [(128, 60, 3), (256, 40, 35), (256, 24, 16), (128, 50, 33)])
 def test_gru_mfma_recurrence(H, T, N):
     """The 16-sequences-per-workgroup MFMA recurrence (chosen by itself from 32 sequences up, forced
-    here) against the oracle, incl. partly filled sequence groups, and run-to-run identical."""
+    here) against the oracle, incl. partly filled sequence groups, and run-to-run identical -- in its eight-wave form
+    (the default) and in the four-wave form (gru_mfma4 = 1: all weights in registers, gate weights named as
+    accumulator-file operands of hand-placed matrix instructions; kept as a measured alternative), which sums every
+    product in the same order and must therefore give the same bits."""
     import modules
+    from conftest import poison_gpu_state
     rng = np.random.RandomState(H + T + N)
     st = _store('bfloat16')
     x = torch.from_numpy((0.7 * rng.standard_normal((N, T, H))).astype(np.float32))
     xd = modules.convert(x.cuda(), st.dtype)
     _vc.set_option('gru_mfma', 1)
-    with modules.variable_store(st), modules.variable_scope('g'):
-        y = modules.gru(xd, num_units=H, bidirection=True)
-        y2 = modules.gru(xd, num_units=H, bidirection=True)
-        _vc.set_option('gru_mfma', 0)
-        yv = modules.gru(xd, num_units=H, bidirection=True)
+    try:
+        with modules.variable_store(st), modules.variable_scope('g'):
+            y = modules.gru(xd, num_units=H, bidirection=True)
+            poison_gpu_state()                                # stale LDS (the ring, h) and workspace must not matter
+            y2 = modules.gru(xd, num_units=H, bidirection=True)
+            _vc.set_option('gru_mfma4', 1)
+            y8 = modules.gru(xd, num_units=H, bidirection=True)
+            _vc.set_option('gru_mfma4', -1)
+            _vc.set_option('gru_mfma', 0)
+            yv = modules.gru(xd, num_units=H, bidirection=True)
+    finally:
+        _vc.set_option('gru_mfma4', -1)
+        _vc.set_option('gru_mfma', -1)
+    assert not torch.isnan(y.float()).any()
     assert torch.equal(y, y2)
+    assert torch.equal(y, y8), (y.float() - y8.float()).abs().max().item()
     cast = lambda t: t.float().bfloat16().double()
     w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
     ref = mo.gru_bidirectional(cast(x), w, 'g/gru')
