@@ -85,7 +85,7 @@ def _oracle_step(cfg, w, ppg, t_mel, t_stft, seed_base, taps=None, f_mel_pred=No
     ml, sl, loss = mo.decoder_loss(ym, ys, torch.from_numpy(t_mel).double(), torch.from_numpy(t_stft).double(), cfg)
     loss.backward()
     grads = {k: v.grad.numpy() for k, v in wt.items() if v.requires_grad}
-    return float(ml), float(sl), grads, stats, ym.detach().numpy(), ys.detach().numpy()
+    return float(ml.detach()), float(sl.detach()), grads, stats, ym.detach().numpy(), ys.detach().numpy()
 
 
 @pytest.mark.parametrize('dropout,loss_type', [(0.1, 'sum'), (0.0, 'log')])
@@ -519,6 +519,62 @@ def test_data_parallel_two_ranks(tmp_path):
     assert r.returncode == 0 and line, r.stdout[-3000:] + r.stderr[-3000:]
     res = json.loads(line[0].split(' ', 1)[1])
     assert res['grad_err'] < 1e-6 and res['param_err'] < 1e-6 and res['replicas_equal'], res
+
+
+@pytest.mark.parametrize('N,T,H', [(3, 9, 64), (131, 7, 64), (259, 5, 128), (130, 6, 256)])
+def test_training_recurrence_window_groups_match_autograd(N, T, H):
+    """vc_gru_train_forward / vc_gru_backward (/root/reference/modules.py:168-204 under tf.gradients) at batch sizes that
+    select the kernels which advance 2 or 4 windows per workgroup (more than 128 / 256 windows per GPU, ragged last
+    group included; 3 windows: the one-window kernels): hidden states, saved gates, r*h, and the gradient w.r.t. the
+    gate pre-activations against float64 autograd of the recurrence restated here from the oracle's cell
+    (model_oracle.gru_direction: r, u = sigmoid([x, h] Wg + bg); c = tanh([x, r*h] Wc + bc); h' = u h + (1 - u) c), with
+    the input projections given.  Tolerance 2e-5 forward, 1e-4 of the gradient's max backward (float32 sums over H
+    products per step, chained over T steps)."""
+    import ctypes as C
+    import _vc
+    rng = np.random.RandomState(N + H)
+    M = N * T
+    xp = torch.from_numpy(rng.standard_normal((M, 6 * H)) * 0.5)
+    wh = [torch.from_numpy(rng.standard_normal((H, 3 * H)) * (1.0 / np.sqrt(H))) for _ in range(2)]
+    dG = torch.from_numpy(rng.standard_normal((M, 2 * H)))
+    # float64 reference with autograd
+    xr = xp.clone().requires_grad_(True)
+    outs = []
+    for d in range(2):
+        x3 = xr.view(N, T, 6 * H)[:, :, d * 3 * H:(d + 1) * 3 * H]
+        h = torch.zeros((N, H), dtype=torch.float64)
+        hs = [None] * T
+        for t in (range(T) if d == 0 else range(T - 1, -1, -1)):
+            g = torch.sigmoid(x3[:, t, :2 * H] + h @ wh[d][:, :2 * H])
+            r, u = g[:, :H], g[:, H:]
+            c = torch.tanh(x3[:, t, 2 * H:] + (r * h) @ wh[d][:, 2 * H:])
+            h = u * h + (1 - u) * c
+            hs[t] = h
+        outs.append(torch.stack(hs, 1))
+    G_ref = torch.cat(outs, 2).reshape(M, 2 * H)
+    (G_ref * dG).sum().backward()
+    # device
+    f = lambda t: t.float().cuda().contiguous()
+    xd, w0, w1, dGd = f(xp), f(wh[0]), f(wh[1]), f(dG)
+    G = torch.empty((M, 2 * H), device='cuda')
+    gates = torch.empty((2, M, 3 * H), device='cuda')
+    rh = torch.empty((2, M, H), device='cuda')
+    p = lambda t: C.c_void_p(t.data_ptr())
+    _vc.check(_vc.lib().vc_gru_train_forward(p(xd), p(w0), p(w1), N, T, H, p(G), p(gates), p(rh), _vc.current_stream()))
+    dpre = torch.empty((M, 6 * H), device='cuda')
+    w0t, w1t = w0.t().contiguous(), w1.t().contiguous()
+    _vc.check(_vc.lib().vc_gru_backward(p(dGd), p(G), p(gates), p(w0), p(w1), p(w0t), p(w1t), N, T, H, p(dpre), _vc.current_stream()))
+    torch.cuda.synchronize()
+    assert float((G.cpu().double() - G_ref.detach()).abs().max()) < 2e-5
+    gref = xr.grad
+    err = float((dpre.cpu().double() - gref).abs().max() / gref.abs().max())
+    assert err < 1e-4, err
+    # saved gates (r | u | c) and r*h of the forward direction at the first step: h = 0 there
+    x0 = xp.view(N, T, 6 * H)[:, 0, :3 * H]
+    g0 = gates[0].view(N, T, 3 * H)[:, 0].cpu().double()
+    assert float((g0[:, :2 * H] - torch.sigmoid(x0[:, :2 * H])).abs().max()) < 2e-6
+    assert float((g0[:, 2 * H:] - torch.tanh(x0[:, 2 * H:])).abs().max()) < 2e-6
+    assert float(rh[0].view(N, T, H)[:, 0].abs().max()) == 0.0
 
 
 def test_encoder_train_step_matches_autograd(golden_dir):
