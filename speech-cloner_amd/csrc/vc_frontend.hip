@@ -629,6 +629,12 @@ struct vc_frontend_plan {
     void* d_blob;
     FeDev dev;
     const float* d_dct_half;      // [n_mfcc][n_mels / 2] (fast400 only)
+    // one-launch form (fast400): two sets of per-utterance arrival counters owned by the plan, zero from creation on.
+    // Launch n counts in set n & 1 and zeroes the other one, which launch n - 1 used and -- the launches of a plan being
+    // ordered on their stream -- has finished with: no memset between launches, and a late arrival of a launch whose
+    // waiters had given up still lands before anybody reads that set again.
+    unsigned* d_fcount;
+    mutable unsigned fused_launches;
 };
 
 extern "C" {
@@ -650,6 +656,8 @@ int vc_frontend_plan_create(const vc_frontend_cfg* cfg, const double* h_window, 
     p->mfcc_width = cfg->n_mfcc * (cfg->calc_mfcc_derivate ? 2 : 1);
     p->fft400 = (cfg->n_fft == 400);
     p->d_blob = nullptr;
+    p->d_fcount = nullptr;
+    p->fused_launches = 0;
     build_mel(cfg->sample_rate, cfg->n_fft, cfg->n_mels, p->mel);
     build_dct(cfg->n_mfcc, cfg->n_mels, p->dct);
 
@@ -728,6 +736,12 @@ int vc_frontend_plan_create(const vc_frontend_cfg* cfg, const double* h_window, 
     p->d_dct_half = df + o_dcth;
     p->dev.mel_start = reinterpret_cast<int32_t*>(df + o);
     p->dev.mel_off = p->dev.mel_start + NM;
+    if (p->fast400) {
+        const size_t nb = 2 * (size_t)vc_fe400_fused_count_bytes(FE400_FUSED_MAX_BATCH);
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_fcount), nb);
+        if (e == hipSuccess) e = hipMemset(p->d_fcount, 0, nb);
+        if (e != hipSuccess) { (void)hipFree(p->d_blob); delete p; return vc::set_error(VC_ERR_HIP, "front-end counters: %s", hipGetErrorString(e)); }
+    }
     *out_plan = p;
     return VC_OK;
 }
@@ -735,6 +749,7 @@ int vc_frontend_plan_create(const vc_frontend_cfg* cfg, const double* h_window, 
 void vc_frontend_plan_destroy(vc_frontend_plan* plan) {
     if (!plan) return;
     if (plan->d_blob) (void)hipFree(plan->d_blob);
+    if (plan->d_fcount) (void)hipFree(plan->d_fcount);
     delete plan;
 }
 
@@ -807,8 +822,27 @@ int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, con
         f.stats = reinterpret_cast<float*>(wsb + o_stats);
         f.mel0 = reinterpret_cast<float*>(wsb + o_mel);
         f.nt1 = ntiles;
+        // one-launch form: tile records in the mel slot (batch x max_frames x 80 floats, of which this path uses only frame
+        // 0's rows): [mel0 | records]; arrival counters in the plan's own double-buffered block
+        const size_t o_rec = align256((size_t)batch * c.n_mels * 4);
+        f.fstride = vc_fe400_fused_stride(max_frames);
+        f.fstats = reinterpret_cast<float*>(wsb + o_mel + o_rec);
+        const bool room = o_rec + (size_t)batch * f.fstride * 4 <= total - o_mel && batch <= FE400_FUSED_MAX_BATCH;
+        // Chosen by itself only while every workgroup of the launch is resident at once (256 CUs x 4): a waiting block
+        // keeps its slot, so past one round of workgroups the second round starts behind the first one's waits and the
+        // form loses what the saved transform had won (tools/fe_fused_probe.py: 27.4 vs 30.3 us at 17 utterances of 4 s,
+        // 47.8 vs 47.3 at 32, 88.9 vs 77.8 at 64).  vc_set_option("fe_fused", 1 / 0) forces either.
+        const int fopt = vc::opt(vc::OPT_FE_FUSED);
+        const long fused_blocks = (long)batch * ((max_frames + 13) / 14);
+        const bool fused = room && (stage_mask & 6) == 6 && vc_fe400_fused_ok(max_frames) &&
+                           (fopt == 1 || (fopt != 0 && fused_blocks <= 1024));
+        const unsigned par = plan->fused_launches & 1;
+        const size_t set_words = (size_t)vc_fe400_fused_count_bytes(FE400_FUSED_MAX_BATCH) / 4;
+        f.fcount = plan->d_fcount + par * set_words;
+        f.fcount_other = plan->d_fcount + (par ^ 1) * set_words;
+        if (fused) ++plan->fused_launches;
         f.mfcc = d_mfcc; f.mel_db = d_mel_db; f.pow_db = d_pow_db;
-        return vc_fe400_launch(f, batch, stage_mask, static_cast<hipStream_t>(stream));
+        return vc_fe400_launch(f, batch, stage_mask, fused ? 1 : 0, static_cast<hipStream_t>(stream));
     }
     const int G = plan->fft400 ? FE_G400 : FE_GGEN;
     FeArgs a;

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+constexpr int FE400_FUSED_MAX_BATCH = 1024;   // utterances per launch the plan's counter sets are sized for
+
 struct Fe400Args {
     const float* wav;
     const int32_t* lens;
@@ -19,10 +21,21 @@ struct Fe400Args {
     float* stats;                 // [B][nt1][8]: max P, min P, max mel, min mel, sum|x| per 16-frame tile (linear)
     float* mel0;                  // [B][80]: frame 0's mel power
     int32_t nt1;                  // 16-frame tiles per utterance (over max_frames)
+    // one-launch form (vc_frontend400.hip, fe400_fused_kernel): 14-frame tiles
+    float* fstats;                // [B][fstride] floats: tile records of 8 floats, each utterance's array padded to whole 128-B lines
+    int32_t fstride;              // floats per utterance in fstats (a multiple of 32)
+    unsigned* fcount;             // [FE400_FUSED_MAX_BATCH] (one per 256 bytes): tiles of the utterance that have published (zero at launch)
+    unsigned* fcount_other;       // the set the previous launch used: zeroed by this launch for the next one
+    int32_t spin_limit;           // polls before a waiting block computes the utterance's records itself (set by the launcher)
     float* mfcc;
     float* mel_db;
     float* pow_db;
 };
 
-// stage_mask: 2 = statistics pass, 4 = feature pass
-int vc_fe400_launch(const Fe400Args& a, int batch, int stage_mask, hipStream_t st);
+// stage_mask: 2 = statistics pass, 4 = feature pass; with `fused` != 0 (both stages asked for, vc_fe400_fused_ok) they run
+// as ONE launch (fe400_fused_kernel)
+int vc_fe400_launch(const Fe400Args& a, int batch, int stage_mask, int fused, hipStream_t st);
+// floats of fstats per utterance for max_frames frames, and whether the one-launch form takes such utterances
+int vc_fe400_fused_stride(int max_frames);
+int vc_fe400_fused_count_bytes(int batch);
+bool vc_fe400_fused_ok(int max_frames);

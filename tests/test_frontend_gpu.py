@@ -157,6 +157,79 @@ def test_stored_rows_can_be_fewer_than_the_frames():
         audio_lib.calc_MFCC_input_batch(d, lens, out_frames=400, **FE_KW_GENERIC)
 
 
+def test_one_launch_form_equals_two_pass_and_never_depends_on_waiting():
+    """The shipped configuration can run as ONE launch (csrc/vc_frontend400.hip, fe400_fused_kernel: every frame transformed
+    once; a block publishes its tile record, waits for the tiles of its own utterance, finishes from LDS) -- chosen by
+    itself for launches whose workgroups are all resident at once, forced here (fe_fused = 1) also for the benchmark's
+    batch, which takes two rounds of workgroups.
+      * against the two-launch form (option fe_fused = 0) the extremes are identical and sum|x| differs only in
+        summation order: features equal to 2e-6, and both within the front-end tolerances of the oracle;
+      * a block whose poll runs out computes the utterance's records itself: with fe_fused_spin = 0 EVERY block takes that
+        path -- walk all tiles, restore its own -- and the result must be bit-identical to the waiting path;
+      * bit-identical from run to run with NaN-poisoned LDS / workspace and an unrelated stream keeping CUs busy (uneven
+        arrival of an utterance's tiles)."""
+    import torch
+    import _vc
+    import audio_lib
+    import modules
+    from conftest import poison_gpu_state
+    rng = np.random.RandomState(17)
+    lens = [16000, 15999, 1119, 8000, 201, 12345]
+    L = max(lens)
+    wav = np.zeros((len(lens), L), np.float32)
+    for b, n in enumerate(lens):
+        wav[b, :n] = fo.synth_speech(1, n, seed=20 + b)[0] * (0.2 + 0.3 * b)
+    d = torch.from_numpy(wav).cuda()
+    _vc.set_option('fe_fused', 1)
+    try:
+        _one_launch_checks(d, wav, lens)
+    finally:
+        _vc.set_option('fe_fused', -1)
+
+
+def _one_launch_checks(d, wav, lens):
+    import torch
+    import _vc
+    import audio_lib
+    import modules
+    from conftest import poison_gpu_state
+    fused = audio_lib.calc_MFCC_input_batch(d, lens, **FE_KW)
+    with _vc.options(fe_fused=0):
+        two = audio_lib.calc_MFCC_input_batch(d, lens, **FE_KW)
+    for name, f_, t_ in zip(('mfcc', 'mel', 'pdb'), fused, two):
+        assert torch.isfinite(f_).all()
+        assert float((f_ - t_).abs().max()) < 2e-6, name
+    for b in (0, 2, 4):
+        F = 1 + lens[b] // 80
+        ref = fo.calc_MFCC_input(wav[b, :lens[b]], **FE_KW)
+        for name, t, r in zip(('mfcc', 'mel', 'pdb'), fused, ref):
+            _cmp(t[b, :F].cpu().numpy(), r, TOL[name], 'one launch %s len %d' % (name, lens[b]))
+    # nobody waits: every block walks its utterance
+    with _vc.options(fe_fused_spin=0):
+        poison_gpu_state()
+        alone = audio_lib.calc_MFCC_input_batch(d, lens, **FE_KW)
+        part = audio_lib.calc_MFCC_input_batch(d, lens, out_frames=100, **FE_KW)
+    for name, f_, a_, p_ in zip(('mfcc', 'mel', 'pdb'), fused, alone, part):
+        assert torch.equal(f_, a_), name
+        assert torch.equal(f_[:, :100], p_), name
+    # the benchmark's batch, under uneven load, repeated
+    big = torch.from_numpy(fo.synth_speech(32, 64000, seed=3)).cuda()
+    ref = audio_lib.calc_MFCC_input_batch(big, None, out_frames=800, **FE_KW)
+    noise_stream = torch.cuda.Stream()
+    noise_store = modules.VariableStore('bfloat16')
+    noise_x = torch.randn(16, 400, 256, device='cuda').to(torch.bfloat16)
+    for rep in range(3):
+        poison_gpu_state()
+        if rep:
+            with torch.cuda.stream(noise_stream), modules.variable_store(noise_store), modules.variable_scope('noise'):
+                for _ in range(4):
+                    modules.conv1d_banks(noise_x, K=32, is_training=False)
+        again = audio_lib.calc_MFCC_input_batch(big, None, out_frames=800, **FE_KW)
+        for name, f_, a_ in zip(('mfcc', 'mel', 'pdb'), ref, again):
+            assert torch.equal(f_, a_), (name, rep)
+    torch.cuda.synchronize()
+
+
 def test_errors_are_loud():
     import torch
     import _vc

@@ -24,9 +24,17 @@ names1 = ['entry -> own samples in LDS (wave 0)', '25-point stage, twiddle, row 
 names2 = ['entry -> own samples in LDS (wave 0, incl. the utterance constants)', '25-point stage', '16-point stage', 'power rows',
           'barrier (power tile complete)', 'P_dB out', 'mel dB + barrier', 'M_dB out + sum/diff + barrier', 'DCT + barrier',
           'MFCC / delta out']
-for mask, nblk, names in ((2, nt1, names1), (4, (mf + 13) // 14, names2)):
+names3 = ['entry -> own samples in LDS', '25-point stage', '16-point stage, power rows', 'barrier (power tile complete)',
+          'mel power + reductions + barrier', 'publish + WAIT for the utterance', 'gather + constants + barrier', 'P_dB out', 'mel dB + barrier',
+          'M_dB out + sum/diff + barrier', 'DCT + barrier', 'MFCC / delta out']
+passes = ((6, (mf + 13) // 14, names3),) if (len(sys.argv) > 1 and sys.argv[1] == 'fused') else ((2, nt1, names1), (4, (mf + 13) // 14, names2))
+for mask, nblk, names in passes:
     for _ in range(3):
-        out = audio_lib.calc_MFCC_input_batch(wav, None, out=out, stage_mask=mask, **kw)
+        if mask == 6:
+            out = audio_lib.calc_MFCC_input_batch(wav, None, out=out, **kw)
+        else:
+            with _vc.options(fe_fused=0):
+                out = audio_lib.calc_MFCC_input_batch(wav, None, out=out, stage_mask=mask, **kw)
     torch.cuda.synchronize()
     raw = ws.view(torch.uint8)[o_mel + 65536 * 4: o_mel + 65536 * 4 + B * nblk * 16 * 8].view(torch.int64).cpu().numpy().reshape(B * nblk, 16)
     n = len(names) + 1
