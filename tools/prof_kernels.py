@@ -21,12 +21,16 @@ st = modules.VariableStore('bfloat16')
 torch.manual_seed(0)
 with modules.variable_store(st), modules.variable_scope('decoder'), modules.variable_scope('step2'), modules.variable_scope('CBHG'):
     pre = torch.randn(W, T, 256, device='cuda').to(st.dtype)
+    # (the two launches exactly as modules.CBHG issues them: the bank stores its max-pooled result, the projection reads a
+    # plain operand and -- same kernel name, bank256_kernel -- runs only when asked for by name, so that the 'all' passes
+    # keep the filter bank's counters clean)
     if what in ('bank', 'all', 'proj1'):
         for _ in range(reps):
-            bank = modules.conv1d_banks(pre, K=32, is_training=False)
-    if what in ('proj1', 'all'):
-        for _ in range(reps):
-            modules.conv1d(bank, filters=256, size=3, scope="conv1d_1", bn_scope="conv1d_1", activation_fn='relu', pool_input=2)
+            bank, pooled = modules.conv1d_banks(pre, K=32, is_training=False, pool_output='auto')
+    if what == 'proj1':
+        for _ in range(20):
+            modules.conv1d(bank, filters=256, size=3, scope="conv1d_1", bn_scope="conv1d_1", activation_fn='relu',
+                           pool_input=0 if pooled else 2)
     if what in ('gru', 'all'):
         for _ in range(reps):
             modules.gru(pre, num_units=256, bidirection=True)
@@ -38,8 +42,12 @@ if what in ('encfront', 'all'):
 if what in ('frontend', 'all'):
     wav = bench.synth_audio(32, 64000, 0).cuda()
     out = None
-    for _ in range(reps):
+    import _vc
+    for _ in range(reps):                       # the form the library picks at this batch (two launches)
         out = audio_lib.calc_MFCC_input_batch(wav, None, out=out, **bench.FE_KW)
+    with _vc.options(fe_fused=1):               # and the one-launch form, for its counters
+        for _ in range(reps):
+            out = audio_lib.calc_MFCC_input_batch(wav, None, out=out, **bench.FE_KW)
 if what in ('vocoder', 'all'):
     amp = torch.rand(16, 1000, 201, device='cuda') * 0.1
     ph = torch.rand(16, 1000, 201, device='cuda') * 3.14159
