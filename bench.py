@@ -73,8 +73,8 @@ def synth_audio(B, L, seed):
 
 
 def _pmc_traffic(kernel):
-    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/r01/pmc_summary.json)."""
-    for rnd in ('r02', 'r01'):
+    """HBM-side bytes per launch from the committed rocprofv3 --pmc passes (profiles/rNN/pmc_summary.json, newest round first)."""
+    for rnd in ('r03', 'r02', 'r01'):
         try:
             return json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_summary.json')))[kernel]['traffic_bytes_per_launch']
         except Exception:
@@ -285,10 +285,10 @@ class _Pipeline:
 
 def _rocprof_bank_avg():
     """Average duration (ms) of the step-2 filter-bank launch in the committed rocprofv3 --kernel-trace --stats run of
-    tools/prof_kernels.py bank (>= 50 calls), profiles/r02/bank_step2_kernel_stats.csv -- reported beside the live
+    tools/prof_kernels.py bank (>= 50 calls), profiles/rNN/bank_step2_kernel_stats.csv -- reported beside the live
     HIP-event figure so the line can be checked against profiles/."""
     import csv
-    for rnd in ('r02', 'r01'):
+    for rnd in ('r03', 'r02', 'r01'):
         f = os.path.join(ROOT, 'profiles', rnd, 'bank_step2_kernel_stats.csv')
         try:
             for r in csv.DictReader(open(f)):
@@ -343,7 +343,7 @@ def bench_full(args, rank, world):
         # ((2*FETCH_SIZE + WRITE_SIZE) * 1024, gfx950 correction of MI355X_MICROARCH.md)
         traffic = None
         if args.dtype == 'bfloat16' and W == 64:
-            for rnd in ('r02', 'r01'):
+            for rnd in ('r03', 'r02', 'r01'):
                 try:
                     pm = json.load(open(os.path.join(ROOT, 'profiles', rnd, 'pmc_summary.json')))
                     traffic = pm['bank256_kernel_bf16_step2']['traffic_bytes_per_launch']
