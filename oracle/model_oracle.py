@@ -243,16 +243,18 @@ def cbhg(x, w, scope, K, n_highway, is_training=False, stats_out=None, taps=None
 
 
 # --------------------------------------------------------------------------- models
-def encoder_forward(x, w, cfg, scope=None, taps=None, is_training=False, masks=None, stats_out=None):
+def encoder_forward(x, w, cfg, scope=None, taps=None, is_training=False, masks=None, stats_out=None, routing=None):
     """encoder.py:78-123.  Inference mode by default; ``is_training`` switches batch norm to batch
-    statistics and ``masks`` = (mask1, mask2) are the prenet dropout keep-masks.
+    statistics and ``masks`` = (mask1, mask2) are the prenet dropout keep-masks.  ``routing``: optional dict of given
+    relu / pool decisions ('prenet' -> (on1, on2) and the keys cbhg takes; see conv1d_banks).
     Returns (y_logits, y_pred, y_pred_class, CBHG_out)."""
     scope = scope or cfg.get('model_name', 'encoder')
-    pre = prenet(x, w, scope + '/prenet', cfg['dropout_rate'], masks)
+    routing = routing or {}
+    pre = prenet(x, w, scope + '/prenet', cfg['dropout_rate'], masks, routing.get('prenet'))
     if taps is not None:
         taps['prenet'] = pre
     out = cbhg(pre, w, scope + '/CBHG', cfg['num_conv_banks'], cfg['num_highwaynet_blocks'],
-               is_training, stats_out, taps=taps)
+               is_training, stats_out, taps=taps, routing=routing)
     logits = dense(out, w, scope + '/y_logits')
     pred = torch.softmax(logits, dim=-1)
     cls = torch.argmax(logits, dim=-1).to(torch.int32)

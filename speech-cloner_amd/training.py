@@ -408,8 +408,9 @@ class StageTrainer:
             Xi = sv['Ys'][i]
             pre = torch.empty((M, NP), dtype=torch.float32, device=dev)
             gemm_launch(Xi, M, T_, H, H, NP, [(bt, H, 1, 0, 0)], pre, NP, f32, epi_shift=bias, out_f32=True)
-            if self.export_routing and H % 32 == 0:       # vc_highway_backward: dense1's relu passes where its re-computed
-                self.routing[s]['highway'][i] = (pre.view(M, H // 32, 2, 32)[:, :, 0, :] > 0).reshape(N_, T_, H)   # pre-activation > 0
+            if self.export_routing:        # vc_highway_backward: dense1's relu passes where its re-computed pre-activation > 0
+                j = torch.arange(H, device=dev)            # unit j sits at column 64 (j / 32) + j % 32 of the paired layout
+                self.routing[s]['highway'][i] = (pre[:, 64 * (j // 32) + j % 32] > 0).view(N_, T_, H)
             dp = torch.empty((M, NP), dtype=torch.float32, device=dev)
             dXd = torch.empty((M, H), dtype=torch.float32, device=dev)
             _vc.check(_lib().vc_highway_backward(_p(pre), NP, _p(Xi), _p(dYc), M, H, _p(dp), _p(dXd), _st()))

@@ -581,7 +581,14 @@ def test_encoder_train_step_matches_autograd(golden_dir):
     """Encoder training (encoder.py:134-194, 256-297) at the shipped
     hyper-parameters (E = 80, K = 6, 61 classes, 400 frames) starting from the reference's real
     enc_14 weights: loss / accuracy / mse, every gradient, and the Adam resume from the
-    checkpoint's own slots."""
+    checkpoint's own slots.  Relu / max-pool routing is the device's own (see
+    test_hp_size_train_step_matches_autograd): every element of every gradient within 1e-4 of its tensor's maximum
+    (it was 3e-3 with the oracle routing by itself) -- at 2 windows and at the training batch of the shipped
+    configuration, 32 windows.  The windows are the golden ones at their natural amplitude, shifted in time: with the
+    same windows scaled to 0.5-1.0 the TRAINED recurrence has, in one window of 32, a stretch where it amplifies
+    differences (float32 against float64: 7e-7 in the state at step 0, x10 every ~35 steps from step 100 on, 4e-4 at
+    step 399 -- smooth exponential growth from rounding level, measured on the saved gates), and a comparison of a
+    float32 trajectory with a float64 one then measures the number format, not the kernels."""
     import os
     from conftest import ROOT
     from encoder import encoder_spec_phn
@@ -591,39 +598,48 @@ def test_encoder_train_step_matches_autograd(golden_dir):
     enc = encoder_spec_phn(cfg, None)
     enc.restore()
     g = np.load(os.path.join(golden_dir, 'encoder_fwd.npz'))
-    x = g['x'][:2]
-    rng = np.random.RandomState(4)
-    labels = rng.randint(0, 61, (2, 400))
-    target = np.eye(61, dtype=np.float32)[labels]
-    tr = enc._get_trainer()
-    out3 = tr.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(target).cuda())
-    # oracle with the same dropout masks
-    M, keep = 800, 1.0 - cfg['dropout_rate']
-    sb = tr.seed + 1000 * tr.step_count
-    masks = (torch.from_numpy(_mask(M, 80, 80, sb + 1, keep)).view(2, 400, 80),
-             torch.from_numpy(_mask(M, 40, 40, sb + 2, keep)).view(2, 400, 40))
     w = tf_bundle.read_bundle(os.path.join(golden_dir, 'enc_14_ckpt', 'encoder-136512'))
-    wt = mo.to_torch({k: v for k, v in w.items() if k.startswith('encoder/')}, torch.float64, requires_grad=True)
-    stats = {}
-    lg, _, _, _ = mo.encoder_forward(torch.from_numpy(x).double(), wt, cfg, is_training=True, masks=masks, stats_out=stats)
-    loss = mo.encoder_loss(lg, torch.from_numpy(target).double())
-    acc, mse = mo.encoder_metrics(lg.detach(), torch.from_numpy(target).double())
-    loss.backward()
-    got = out3.cpu().numpy()
-    assert abs(got[0] - float(loss)) < 1e-4 * max(1.0, float(loss)), (got, float(loss))
-    assert abs(got[1] - float(acc)) < 1e-6 + 1.0 / M and abs(got[2] - float(mse)) < 1e-6
-    worst = ('', 0.0)
-    for n in tr.names:
-        ref = wt[n].grad.numpy()
-        err = np.abs(tr.g(n).cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-7)
-        if err > worst[1]:
-            worst = (n, err)
-    assert worst[1] < 3e-3, 'worst gradient mismatch %s: %.3e' % worst
+    w = {k: v for k, v in w.items() if k.startswith('encoder/')}
+    tr = enc._get_trainer()
+    tr.export_routing = True
+    keep = 1.0 - cfg['dropout_rate']
+    for N in (2, cfg['batch_size']):
+        rng = np.random.RandomState(4 + N)
+        x = np.stack([np.roll(g['x'][i % 3], 16 * int(rng.randint(0, 25)), axis=0) for i in range(N)]).astype(np.float32)
+        labels = rng.randint(0, 61, (N, 400))
+        target = np.eye(61, dtype=np.float32)[labels]
+        M = N * 400
+        out3 = tr.forward_backward(torch.from_numpy(x).cuda(), torch.from_numpy(target).cuda())
+        rt = _device_routing(tr)['encoder']
+        sb = tr.seed + 1000 * tr.step_count
+        masks = (torch.from_numpy(_mask(M, 80, 80, sb + 1, keep)).view(N, 400, 80),
+                 torch.from_numpy(_mask(M, 40, 40, sb + 2, keep)).view(N, 400, 40))
+        wt = mo.to_torch(w, torch.float64, requires_grad=True)
+        stats = {}
+        lg, _, _, _ = mo.encoder_forward(torch.from_numpy(x).double(), wt, cfg, is_training=True, masks=masks, stats_out=stats,
+                                         routing=rt)
+        loss = mo.encoder_loss(lg, torch.from_numpy(target).double())
+        acc, mse = mo.encoder_metrics(lg.detach(), torch.from_numpy(target).double())
+        loss.backward()
+        got = out3.cpu().numpy()
+        assert abs(got[0] - float(loss)) < 1e-5 * max(1.0, float(loss)), (got, float(loss))
+        assert abs(got[1] - float(acc)) < 1e-6 + 1.0 / M and abs(got[2] - float(mse)) < 1e-6
+        worst = ('', 0.0)
+        for n in tr.names:
+            ref = wt[n].grad.numpy()
+            err = np.abs(tr.g(n).cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-7)
+            if err > worst[1]:
+                worst = (n, err)
+        print('encoder N=%d: worst gradient mismatch %s %.3e' % ((N,) + worst))
+        assert worst[1] < 1e-4, 'N=%d: worst gradient mismatch %s: %.3e' % ((N,) + worst)
+        # (the moving statistics this forward produced, against the oracle's from the same starting values)
+        for n_, v_ in stats.items():
+            assert np.abs(enc.store.vars[n_].cpu().numpy() - v_.numpy()).max() < 1e-5 * max(1.0, float(v_.abs().max())), n_
+        w.update({n_: v_.numpy().astype(np.float32) for n_, v_ in stats.items()})       # the device moved them in place
     # a full step resumes Adam from the reference's own slots (beta powers are 0 after 136k steps)
-    slots = tf_bundle.read_bundle(os.path.join(ROOT, 'tests', 'golden', 'enc_14_ckpt', 'encoder-136512'))
-    r = enc.exec_train_step(x, target)
+    r = enc.exec_train_step(x[:2], target[:2])
     assert r[3] == 136513 and r[4] is None and np.isfinite(r[0])
-    a_, m_, l_ = enc.exec_calc_metrics(x, target)
+    a_, m_, l_ = enc.exec_calc_metrics(x[:2], target[:2])
     assert 0.0 <= a_ <= 1.0 and np.isfinite(l_)
 
 
