@@ -387,6 +387,17 @@ int vc_axpby(const float* d_X, int32_t ldx, float a, const float* d_Y, int32_t l
  * left untouched).  d_workspace: 256 floats; d_loss: 1 float on the device (no host sync). */
 int vc_mse_loss(const float* d_y, const float* d_t, size_t n, float weight, float* d_dY, int32_t C, int32_t ld_dy,
                 float* d_loss, float* d_workspace, void* stream);
+/* LSTM recurrence in training mode (use_lstm; /root/reference/modules.py:207-243: tf.contrib.rnn.LSTMCell, forget_bias 1.0,
+ * under bidirectional_dynamic_rnn): d_xproj [n_seq*T, 8H] = per direction the input projections (i | j | f | o) incl. bias,
+ * d_Wh_* [H, 4H] the recurrent rows of the cell kernel; stores the hidden states d_out [n_seq*T, 2H], the ACTIVATED gates
+ * d_gates [2][n_seq*T, 4H] and the cell states d_cstate [2][n_seq*T, H].  float32, H <= 512.  (No shipped configuration
+ * enables use_lstm: any-size kernels, not tuned ones.) */
+int vc_lstm_train_forward(const float* d_xproj, const float* d_Wh_fw, const float* d_Wh_bw, int32_t n_seq, int32_t T,
+                          int32_t H, float* d_out, float* d_gates, float* d_cstate, void* stream);
+/* BPTT of the above: d_dout [n_seq*T, 2H] -> d_dpre [n_seq*T, 8H], the gradient w.r.t. the gate pre-activations in the
+ * layout of d_xproj.  d_WhT_* [4H, H]: the recurrent weights transposed. */
+int vc_lstm_backward(const float* d_dout, const float* d_gates, const float* d_cstate, const float* d_WhT_fw,
+                     const float* d_WhT_bw, int32_t n_seq, int32_t T, int32_t H, float* d_dpre, void* stream);
 /* Encoder loss and metrics (/root/reference/encoder.py:134-150): out3 = [mean softmax cross-entropy
  * with float labels, accuracy of argmax(logits) vs argmax(target), mean squared error of the
  * posteriors]; optional d_dlogits [M, ldd] = (softmax * sum(target) - target) / M.

@@ -139,6 +139,8 @@ _SIGS = {
     'vc_affine_act': (C.c_int, [_P, _P, _P, C.c_int32, _P, _P, C.c_size_t, C.c_int32, _P]),
     'vc_bn_backward': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P,
                                  C.c_int32, _P, _P, _P, _P, _P]),
+    'vc_lstm_train_forward': (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
+    'vc_lstm_backward': (C.c_int, [_P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
     'vc_bn_post_routing': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P]),
     'vc_relu_dropout_backward': (C.c_int, [_P, _P, C.c_float, _P, C.c_size_t, _P]),
     'vc_highway_backward': (C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),

@@ -759,6 +759,119 @@ gru_train_fwd_ms_kernel(GruTrainArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------- LSTM (use_lstm), training mode
+// tf.contrib.rnn.LSTMCell(num_units, forget_bias = 1.0) under bidirectional_dynamic_rnn (/root/reference/modules.py:207-243):
+//   z = [x, h] W + b, (i, j, f, o) = split(z);  c' = c sig(f + 1) + sig(i) tanh(j);  h' = tanh(c') sig(o).
+// No shipped configuration sets use_lstm, so these are plain any-size kernels (one workgroup per (window, direction), the
+// recurrent weights streamed from L2), not tuned ones.  Forward saves the ACTIVATED gates (i | j | f | o) and the cell state.
+struct LstmTrainArgs {
+    const float* xproj;      // [n_seq*T, 8H]
+    const float* Wh[2];      // [H, 4H]
+    float* out;              // [n_seq*T, 2H]
+    float* gates;            // [2][n_seq*T, 4H]
+    float* cst;              // [2][n_seq*T, H]
+    int32_t n_seq, T, H;
+};
+
+__global__ void __launch_bounds__(512)
+lstm_train_fwd_kernel(LstmTrainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.H, H4 = 4 * H, NT = blockDim.x, tid = threadIdx.x;
+    float* h = reinterpret_cast<float*>(smem);      // [H]
+    float* z = h + H;                               // [4H]
+    const int seq = blockIdx.x, dir = blockIdx.y;
+    const float* W = a.Wh[dir];
+    const size_t MT = (size_t)a.n_seq * a.T;
+    float* gates = a.gates + (size_t)dir * MT * H4;
+    float* cst = a.cst + (size_t)dir * MT * H;
+    for (int i = tid; i < H; i += NT) h[i] = 0.0f;
+    float c = 0.0f;                                 // cell state of unit tid (H <= NT: checked by the host)
+    const size_t xrow = 8 * (size_t)H;
+    const float* xbase = a.xproj + (size_t)seq * a.T * xrow + (size_t)dir * H4;
+    __syncthreads();
+    int t = dir ? a.T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    for (int step = 0; step < a.T; ++step, t += dt) {
+        const float* xr = xbase + (size_t)t * xrow;
+        for (int col = tid; col < H4; col += NT) {
+            float acc = xr[col];
+            const float* w = W + col;
+#pragma unroll 4
+            for (int k = 0; k < H; ++k) acc = fmaf(h[k], w[(size_t)k * H4], acc);
+            z[col] = acc;
+        }
+        __syncthreads();
+        if (tid < H) {
+            const float gi = sigmoidf_(z[tid]), gj = tanhf(z[H + tid]);
+            const float gf = sigmoidf_(z[2 * H + tid] + 1.0f), go = sigmoidf_(z[3 * H + tid]);
+            c = gf * c + gi * gj;
+            const float hn = go * tanhf(c);
+            h[tid] = hn;
+            const size_t row = (size_t)seq * a.T + t;
+            gates[row * H4 + tid] = gi; gates[row * H4 + H + tid] = gj;
+            gates[row * H4 + 2 * H + tid] = gf; gates[row * H4 + 3 * H + tid] = go;
+            cst[row * H + tid] = c;
+            a.out[row * 2 * H + (size_t)dir * H + tid] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+struct LstmBwdArgs {
+    const float* dout;       // [n_seq*T, 2H]
+    const float* gates;      // [2][n_seq*T, 4H]
+    const float* cst;        // [2][n_seq*T, H]
+    const float* WhT[2];     // [4H, H] transposed recurrent weights
+    float* dpre;             // [n_seq*T, 8H]
+    int32_t n_seq, T, H;
+};
+
+// BPTT: walks the steps of a direction in reverse; dpre = gradient w.r.t. the pre-activations z (the forget bias is a
+// constant), in the layout of xproj.
+__global__ void __launch_bounds__(512)
+lstm_bwd_kernel(LstmBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int H = a.H, H4 = 4 * H, tid = threadIdx.x;
+    float* dz = reinterpret_cast<float*>(smem);     // [4H]
+    const int seq = blockIdx.x, dir = blockIdx.y;
+    const float* WT = a.WhT[dir];
+    const size_t MT = (size_t)a.n_seq * a.T;
+    const float* gates = a.gates + (size_t)dir * MT * H4;
+    const float* cst = a.cst + (size_t)dir * MT * H;
+    float dh_next = 0.0f, dc_next = 0.0f;           // unit tid's, from the step after this one (forward order)
+    int t = dir ? 0 : a.T - 1;                      // last step of the forward pass first
+    const int dt = dir ? 1 : -1;
+    for (int step = 0; step < a.T; ++step, t += dt) {
+        const size_t row = (size_t)seq * a.T + t;
+        if (tid < H) {
+            const float gi = gates[row * H4 + tid], gj = gates[row * H4 + H + tid];
+            const float gf = gates[row * H4 + 2 * H + tid], go = gates[row * H4 + 3 * H + tid];
+            const float c = cst[row * H + tid];
+            const bool first = step == a.T - 1;                       // the forward pass's first step: c_prev = 0
+            const float cp = first ? 0.0f : cst[((size_t)seq * a.T + (t + dt)) * H + tid];
+            const float tc = tanhf(c);
+            const float dh = a.dout[row * 2 * H + (size_t)dir * H + tid] + dh_next;
+            const float dc = dh * go * (1.0f - tc * tc) + dc_next;
+            const float d_o = dh * tc * go * (1.0f - go);
+            const float d_i = dc * gj * gi * (1.0f - gi);
+            const float d_j = dc * gi * (1.0f - gj * gj);
+            const float d_f = dc * cp * gf * (1.0f - gf);
+            dc_next = dc * gf;
+            dz[tid] = d_i; dz[H + tid] = d_j; dz[2 * H + tid] = d_f; dz[3 * H + tid] = d_o;
+            float* dp = a.dpre + row * 8 * (size_t)H + (size_t)dir * H4;
+            dp[tid] = d_i; dp[H + tid] = d_j; dp[2 * H + tid] = d_f; dp[3 * H + tid] = d_o;
+        }
+        __syncthreads();
+        if (tid < H) {
+            float acc = 0.0f;
+#pragma unroll 4
+            for (int col = 0; col < H4; ++col) acc = fmaf(dz[col], WT[(size_t)col * H + tid], acc);
+            dh_next = acc;
+        }
+        __syncthreads();
+    }
+}
+
 struct GruBwdMsArgs {
     GruBwdArgs b;
     const float* WhT[2];     // [3H, H] transposed recurrent weights (coalesced matvecs with W^T)
@@ -1300,6 +1413,30 @@ int vc_gru_backward(const float* d_dout, const float* d_out, const float* d_gate
         else hipLaunchKernelGGL(gru_bwd_ms_kernel<4>, grid, dim3(nt), lds, st, aa);
     } else
         hipLaunchKernelGGL(gru_bwd_kernel, dim3(n_seq, 2), dim3(nt), 5 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_lstm_train_forward(const float* d_xproj, const float* d_Wh_fw, const float* d_Wh_bw, int32_t n_seq, int32_t T,
+                          int32_t H, float* d_out, float* d_gates, float* d_cstate, void* stream) {
+    VC_REQUIRE(d_xproj && d_Wh_fw && d_Wh_bw && d_out && d_gates && d_cstate, "NULL argument");
+    VC_REQUIRE(n_seq > 0 && n_seq <= 65535 && T > 0 && H > 0 && H <= 512, "vc_lstm_train_forward: bad shape n_seq=%d T=%d H=%d (H <= 512)", n_seq, T, H);
+    LstmTrainArgs a;
+    a.xproj = d_xproj; a.Wh[0] = d_Wh_fw; a.Wh[1] = d_Wh_bw; a.out = d_out; a.gates = d_gates; a.cst = d_cstate;
+    a.n_seq = n_seq; a.T = T; a.H = H;
+    hipLaunchKernelGGL(lstm_train_fwd_kernel, dim3(n_seq, 2), dim3(512), 5 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+int vc_lstm_backward(const float* d_dout, const float* d_gates, const float* d_cstate, const float* d_WhT_fw,
+                     const float* d_WhT_bw, int32_t n_seq, int32_t T, int32_t H, float* d_dpre, void* stream) {
+    VC_REQUIRE(d_dout && d_gates && d_cstate && d_WhT_fw && d_WhT_bw && d_dpre, "NULL argument");
+    VC_REQUIRE(n_seq > 0 && n_seq <= 65535 && T > 0 && H > 0 && H <= 512, "vc_lstm_backward: bad shape n_seq=%d T=%d H=%d (H <= 512)", n_seq, T, H);
+    LstmBwdArgs a;
+    a.dout = d_dout; a.gates = d_gates; a.cst = d_cstate; a.WhT[0] = d_WhT_fw; a.WhT[1] = d_WhT_bw; a.dpre = d_dpre;
+    a.n_seq = n_seq; a.T = T; a.H = H;
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3(n_seq, 2), dim3(512), 4 * (size_t)H * 4, static_cast<hipStream_t>(stream), a);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }

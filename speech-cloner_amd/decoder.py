@@ -69,8 +69,6 @@ class decoder_specs:
         scope = c['model_name']
         self._scope = scope
         modules._refuse_cudnn(c['use_Cudnn'], 'decoder_specs')
-        if c['use_lstm'] and c['is_training']:
-            raise NotImplementedError(' - ERROR, use_lstm is built for inference only (no shipped configuration uses it)')
         T, n_in = c['input_shape']
         if self.encoder is None:
             self.inputs = Handle(scope + '/inputs', (None, T, n_in))

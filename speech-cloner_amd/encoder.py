@@ -77,8 +77,6 @@ class encoder_spec_phn:
         if embed_size is None:
             embed_size = input_shape[-1]
         modules._refuse_cudnn(use_Cudnn, 'encoder_spec_phn')
-        if use_lstm and is_training:
-            raise NotImplementedError(' - ERROR, use_lstm is built for inference only (no shipped configuration uses it)')
         self._embed_size = embed_size
         self._scope = scope
         modules.create_stage_variables(self.store, scope, input_shape[-1], embed_size, num_conv_banks,

@@ -14,8 +14,8 @@ and cached; ``VariableStore.invalidate()`` drops them after a weight update.
 
 ``embed`` and ``attention_decoder`` (modules.py:10-36, 246-272) are dead code in the reference
 (never called) and are not provided; ``lstm`` (modules.py:207-243) is reachable only with
-``use_lstm`` true, which no shipped configuration sets: provided for inference (an any-size
-recurrence kernel, not a tuned one); training with use_lstm raises.
+``use_lstm`` true, which no shipped configuration sets: any-size recurrence kernels, not tuned ones
+(inference here; the training step's LSTM lives in training.py / vc_lstm_train_forward, vc_lstm_backward).
 """
 import contextlib
 import ctypes as C
@@ -684,7 +684,7 @@ def CBHG(inputs, embed_size=256, num_conv_banks=16, num_highwaynet_blocks=4, dro
     """modules.py:323-356.  [N, T, E/2] -> [N, T, E]."""
     _refuse_cudnn(use_Cudnn, 'CBHG')
     if use_lstm and is_training:
-        raise NotImplementedError(' - ERROR, CBHG: use_lstm is built for inference only (no shipped configuration sets it)')
+        raise NotImplementedError(' - ERROR, CBHG(is_training=True): training runs through exec_train_step (training.py), not through this function')
     with variable_scope(scope):
         # max pooling (modules.py:331) rides on the bank launch's stores where that kernel can do it,
         # else on conv1d_1's operand load (2: operand is post-ReLU (>= 0), integer-ordered max)

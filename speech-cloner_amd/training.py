@@ -303,16 +303,27 @@ class StageTrainer:
                         mode=_vc.GEMM_HIGHWAY, epi_shift=bias)
             Ys.append(Yn)
         sv['Ys'] = Ys
-        # bidirectional GRU with saved gates
-        gs = s + '/CBHG/gru'
-        btx, bx, wh_fw, wh_bw = modules._prep_gru(st, gs, H, H)
-        xproj = torch.empty((M, 6 * H), dtype=torch.float32, device=dev)
-        gemm_launch(Ys[-1], M, T_, H, H, 6 * H, [(btx, H, 1, 0, 0)], xproj, 6 * H, f32, epi_shift=bx, out_f32=True)
         G = torch.empty((M, 2 * H), dtype=torch.float32, device=dev)
-        gates = torch.empty((2, M, 3 * H), dtype=torch.float32, device=dev)
-        rh = torch.empty((2, M, H), dtype=torch.float32, device=dev)
-        _vc.check(_lib().vc_gru_train_forward(_p(xproj), _p(wh_fw), _p(wh_bw), N_, T_, H, _p(G), _p(gates), _p(rh), _st()))
-        sv.update(G=G, gates=gates, rh=rh, wh=(wh_fw, wh_bw), btx=btx)
+        if self.cfg.get('use_lstm', False):
+            # bidirectional LSTM (modules.py:347-350), saved gates and cell states
+            ls = s + '/CBHG/lstm'
+            btx, bx, wh_fw, wh_bw = modules._prep_lstm(st, ls, H, H, True)
+            xproj = torch.empty((M, 8 * H), dtype=torch.float32, device=dev)
+            gemm_launch(Ys[-1], M, T_, H, H, 8 * H, [(btx, H, 1, 0, 0)], xproj, 8 * H, f32, epi_shift=bx, out_f32=True)
+            gates = torch.empty((2, M, 4 * H), dtype=torch.float32, device=dev)
+            cst = torch.empty((2, M, H), dtype=torch.float32, device=dev)
+            _vc.check(_lib().vc_lstm_train_forward(_p(xproj), _p(wh_fw), _p(wh_bw), N_, T_, H, _p(G), _p(gates), _p(cst), _st()))
+            sv.update(G=G, gates=gates, cst=cst, wh=(wh_fw, wh_bw), btx=btx, lstm=True)
+        else:
+            # bidirectional GRU with saved gates
+            gs = s + '/CBHG/gru'
+            btx, bx, wh_fw, wh_bw = modules._prep_gru(st, gs, H, H)
+            xproj = torch.empty((M, 6 * H), dtype=torch.float32, device=dev)
+            gemm_launch(Ys[-1], M, T_, H, H, 6 * H, [(btx, H, 1, 0, 0)], xproj, 6 * H, f32, epi_shift=bx, out_f32=True)
+            gates = torch.empty((2, M, 3 * H), dtype=torch.float32, device=dev)
+            rh = torch.empty((2, M, H), dtype=torch.float32, device=dev)
+            _vc.check(_lib().vc_gru_train_forward(_p(xproj), _p(wh_fw), _p(wh_bw), N_, T_, H, _p(G), _p(gates), _p(rh), _st()))
+            sv.update(G=G, gates=gates, rh=rh, wh=(wh_fw, wh_bw), btx=btx)
         # output projection, padded row stride so the next stage / backward get 16-byte rows
         y = dense(G, 2 * H, 2 * H, s + '/y_logits', n_out, _vc.ACT_NONE, None, out_ld=modules._pad8(n_out))
         sv['y'] = y
@@ -366,7 +377,51 @@ class StageTrainer:
         dG = self._dgrad_dense(dY, ldy, ldy, self.w(o + '/kernel'), M, T_)
         del GT, dYT
 
-        # ---- GRU
+        # ---- recurrence
+        if sv.get('lstm'):
+            dYc = self._lstm_backward(s, sv, dG)
+        else:
+            dYc = self._gru_backward(s, sv, dG)
+        del dG
+        return self._stage_backward_front(s, sv, dYc, need_dx)
+
+    def _lstm_backward(self, s, sv, dG):
+        """BPTT of the bidirectional LSTM (use_lstm; modules.py:207-243) + its weight gradients; returns the gradient
+        w.r.t. the last highway block's output."""
+        torch = _torch()
+        M, T_, N_ = sv['M'], sv['T'], sv['N']
+        H = sv['E'] // 2
+        dev = dG.device
+        ls = s + '/CBHG/lstm'
+        wh_fw, wh_bw = sv['wh']
+        dpre = torch.empty((M, 8 * H), dtype=torch.float32, device=dev)
+        whT_fw, whT_bw = wh_fw.t().contiguous(), wh_bw.t().contiguous()
+        _vc.check(_lib().vc_lstm_backward(_p(dG), _p(sv['gates']), _p(sv['cst']), _p(whT_fw), _p(whT_bw), N_, T_, H, _p(dpre), _st()))
+        dbx = torch.empty(8 * H, dtype=torch.float32, device=dev)
+        _Ops.col_sum(dpre, M, 8 * H, 8 * H, dbx)
+        dpT, ldp = _Ops.transpose(dpre, M, 8 * H, 8 * H, T_)
+        YT, ldt = _Ops.transpose(sv['Ys'][-1], M, H, H, T_)
+        grp_x = []
+        for d, dn in enumerate(('fw', 'bw')):
+            cell = '{}/bidirectional_rnn/{}/lstm_cell'.format(ls, dn)
+            with _Ops.side(dbx):
+                self.g(cell + '/bias').copy_(dbx[d * 4 * H:(d + 1) * 4 * H])
+            grp_x.append((d * 4 * H, 4 * H, 1, 0, self.g(cell + '/kernel')[:H], 4 * H))          # x rows of the cell kernel
+        _Ops.wgrad(YT, ldt, H, M, T_, dpT, ldp, grp_x)
+        for d, dn in enumerate(('fw', 'bw')):
+            cell = '{}/bidirectional_rnn/{}/lstm_cell'.format(ls, dn)
+            Gd = sv['G'][:, d * H:(d + 1) * H]                                                  # view, ld = 2H
+            HpT, ldh = _Ops.transpose(Gd, M, H, 2 * H, T_, row_shift=(-1 if d == 0 else 1))   # h_{prev}
+            _Ops.wgrad(HpT, ldh, H, M, T_, dpT, ldp, [(d * 4 * H, 4 * H, 1, 0, self.g(cell + '/kernel')[H:], 4 * H)])
+        return self._dgrad_dense(dpre, 8 * H, 8 * H, sv['btx'].t().contiguous(), M, T_)
+
+    def _gru_backward(self, s, sv, dG):
+        """BPTT of the bidirectional GRU + its weight gradients; returns the gradient w.r.t. the last highway block's
+        output."""
+        torch = _torch()
+        M, T_, N_ = sv['M'], sv['T'], sv['N']
+        H = sv['E'] // 2
+        dev = dG.device
         gs = s + '/CBHG/gru'
         wh_fw, wh_bw = sv['wh']
         dpre = torch.empty((M, 6 * H), dtype=torch.float32, device=dev)
@@ -397,8 +452,17 @@ class StageTrainer:
             RT, ldr = _Ops.transpose(sv['rh'][d], M, H, H, T_)
             _Ops.wgrad(RT, ldr, H, M, T_, dpT, ldp, [(d * 3 * H + 2 * H, H, 1, 0, ck[H:], H)])
         # input gradient: dYn = dpre @ Btx  (Btx [6H, H] -> transposed operand [H, 6H])
-        dYc = self._dgrad_dense(dpre, 6 * H, 6 * H, sv['btx'].t().contiguous(), M, T_)
-        del dpT, YT, dpre
+        return self._dgrad_dense(dpre, 6 * H, 6 * H, sv['btx'].t().contiguous(), M, T_)
+
+    def _stage_backward_front(self, s, sv, dYc, need_dx):
+        """Everything in front of the recurrence: highway blocks, projections, filter bank, prenet."""
+        torch = _torch()
+        f32 = _vc.VC_F32
+        M, T_, N_ = sv['M'], sv['T'], sv['N']
+        E, K, n_hw, n_out = sv['E'], sv['K'], sv['n_hw'], sv['n_out']
+        H = E // 2
+        dev = dYc.device
+        inv_keep = 1.0 / self.keep if self.keep < 1.0 else 1.0
 
         # ---- highways (reverse)
         for i in range(n_hw - 1, -1, -1):

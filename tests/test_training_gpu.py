@@ -177,6 +177,51 @@ def test_teacher_forced_stage2_matches_autograd(tmp_path):
         idec.predict(ppg)
 
 
+def test_lstm_stage_train_step_matches_autograd(tmp_path):
+    """use_lstm in training (/root/reference/modules.py:207-243, 347-350 under tf.gradients; no shipped configuration
+    sets it): the CBHG's recurrence is a bidirectional tf.contrib.rnn.LSTMCell (forget_bias 1.0, gates i | j | f | o).
+    One decoder step at a small configuration against autograd on the float64 oracle with the same dropout masks and
+    the device's relu / pool routing: losses 1e-5, every gradient element 1e-4 of its tensor's maximum -- including
+    the LSTM cell kernels and biases of both directions and both stages --; then Adam steps reduce the loss and the
+    checkpoint carries the cells under TF's names.  (TF's LSTMCell itself is recalled from its published source:
+    parity unpinned, as for the inference path.)"""
+    import tf_bundle
+    from decoder import decoder_specs
+    cfg = _cfg()
+    cfg.update(use_lstm=True, model_path=str(tmp_path))
+    dec = decoder_specs(cfg, None, None)
+    rng = np.random.RandomState(8)
+    for n, v in list(dec.store.vars.items()):            # (Glorot kernels from the constructor; everything else perturbed)
+        if n.endswith('bias') or n.endswith('beta') or n.endswith('moving_mean'):
+            dec.store.assign(n, rng.uniform(-0.2, 0.2, tuple(v.shape)).astype(np.float32))
+        elif n.endswith('gamma') or n.endswith('moving_variance'):
+            dec.store.assign(n, rng.uniform(0.5, 1.5, tuple(v.shape)).astype(np.float32))
+    w = {k: v.cpu().numpy().copy() for k, v in dec.store.vars.items()}
+    ppg = torch.softmax(torch.from_numpy(rng.standard_normal((4, 40, 61)) * 2), -1).float().numpy()
+    t_mel = rng.uniform(0, 0.8, (4, 40, 80)).astype(np.float32)
+    t_stft = rng.uniform(0, 0.8, (4, 40, 201)).astype(np.float32)
+    cell = 'decoder/step2/CBHG/lstm/bidirectional_rnn/bw/lstm_cell'
+    assert cell + '/kernel' in dec.store.vars and not any('/gru/' in n for n in dec.store.vars)
+    H2 = cfg['steps_v'][1]['embed_size'] // 2
+    assert tuple(dec.store.vars[cell + '/kernel'].shape) == (2 * H2, 4 * H2)
+    tr = dec._get_trainer()
+    tr.export_routing = True
+    losses = tr.forward_backward(*(torch.from_numpy(a).cuda() for a in (ppg, t_mel, t_stft))).cpu().numpy()
+    g_dev = {n: tr.g(n).cpu().numpy().astype(np.float64) for n in tr.names}
+    ml, sl, grads, stats, ym, ys = _oracle_step(cfg, w, ppg, t_mel, t_stft, tr.seed, routing=_device_routing(tr))
+    assert abs(losses[0] - ml) < 1e-5 * max(1, ml) and abs(losses[1] - sl) < 1e-5 * max(1, sl), (losses, ml, sl)
+    assert np.abs(tr.y_stft.cpu().numpy().reshape(ys.shape) - ys).max() < 1e-4
+    assert np.abs(grads[cell + '/kernel']).max() > 0 and np.abs(grads[cell + '/bias']).max() > 0
+    _compare_gradients(tr, g_dev, grads)
+    r1 = dec.exec_train_step(ppg, t_mel, t_stft)
+    for _ in range(10):
+        r = dec.exec_train_step(ppg, t_mel, t_stft)
+    assert np.isfinite(r[2]) and r[2] < r1[2]
+    dec.save(verbose=False)
+    ck = tf_bundle.read_bundle(tf_bundle.latest_checkpoint(str(tmp_path)))
+    assert ck[cell + '/kernel'].shape == (2 * H2, 4 * H2) and 'dec_opt/' + cell + '/bias/Adam_1' in ck
+
+
 def test_adam_update_and_second_step():
     cfg = _cfg()
     dec, w, ppg, t_mel, t_stft = _setup(cfg)
