@@ -63,6 +63,8 @@ const char* vc_target_arch(void);
  *                    pass); default: one launch while all its workgroups are resident at once (<= 1024 tiles of 14 frames)
  *   "fe_fused_spin"  polls a block of the one-launch front-end waits for the other tiles of its utterance before it
  *                    computes their records itself (default 4000, ~4 ms); 0 = never wait (tests of that path)
+ *   "gru_small_mfma" 1 = the encoder's H = 40 bf16 recurrence with 16 sequences per wave on MFMA instead of one wave per
+ *                    sequence (measured slower; default: off)
  *   "gru_mfma4"      1 = the four-wave MFMA recurrence with all weights in registers (bit-identical, measured slower)
  *   "prenet_lds"     0 = every wave of the fused prenet streams the weights from L2 itself (default: one stream per
  *                    block, shared through LDS)

@@ -41,6 +41,7 @@ enum Option {
     OPT_GRU_MFMA,         // 0: VALU recurrence always, 1: MFMA recurrence always (default: from 32 sequences up)
     OPT_FE_FUSED,         // shipped front-end configuration in one launch: 1 always, 0 never, default while all workgroups are co-resident
     OPT_FE_FUSED_SPIN,    // polls a block of the one-launch front-end waits for its utterance's tiles (default 4000 ~ 4 ms); 0: never wait
+    OPT_GRU_SMALL_MFMA,   // 1: the encoder's H = 40 bf16 recurrence on the 16-sequence MFMA wave (measured slower; default: gru_wave_kernel)
     OPT_GRU_MFMA4,        // 1: the four-wave, all-weights-in-registers MFMA recurrence (measured slower; default: eight waves)
     OPT_PRENET_LDS,       // 0: every wave of prenet_chain streams the weights itself (default: shared through LDS)
     OPT_GRU_TRAIN_RESIDENT,   // 0: the float32 training recurrences stream all their weights from L2 every step

@@ -832,6 +832,180 @@ int launch_mfma4(const GruArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
+// MFMA recurrence for a SMALL hidden size (the encoder: H = 40; bf16): ONE WAVE advances 16 sequences of one direction.
+// All 3H^2 recurrent weights (padded to 48 units x 64 k: 18 fragments = 72 registers) stay in the wave's registers, the
+// 16 hidden-state vectors go through a wave-private LDS tile to change from the accumulator layout (lane = (sequence,
+// 4 units)) into the B-operand layout (lane = (sequence, 8 k)) -- no workgroup barrier anywhere: a wave's LDS operations
+// execute in order.  Against gru_wave_kernel (one wave per SEQUENCE, h broadcast by v_readlane, 0.94 us per step): a
+// step here costs 18 products + the gate arithmetic of 16 x 40 values spread over 64 lanes, and a 64-window batch is 8
+// waves on 2 CUs instead of 128 waves on 32 -- CUs that the register-filling MFMA launches of the other streams cannot
+// use while a single such wave sits on them ("who blocks whom").
+// MEASURED, NOT THE DEFAULT (vc_set_option("gru_small_mfma", 1) selects it): 1.40 us per step against gru_wave_kernel's 0.84
+// (one wave alone on a SIMD pays every latency of the step's dependent chain in full: LDS hand-off, 18 products, 36
+// transcendental pairs per lane), and the pipelined step did not gain from the freed CUs either (1.7655 vs 1.7537 ms;
+// profiles/r03/ab_gru_small_mfma.log).
+template <int H> struct MfsGeom {
+    static constexpr int HP = (H + 15) / 16 * 16, KP = (H + 31) / 32 * 32;
+    static constexpr int TPW = HP / 16, KSN = KP / 32, NF = 3 * TPW * KSN;
+    static constexpr int PITCH = KP + 8;                                 // bf16 elements per LDS row of h
+    static constexpr int WPB = 4;                                        // waves (groups of 16 sequences) per workgroup
+    static constexpr size_t LDS = (size_t)WPB * 2 * 16 * PITCH * 2;
+};
+
+// packed[dir][frag = (g, tl, ks)][lane][8], zero outside the H x H block
+template <int H>
+__global__ void __launch_bounds__(256)
+gru_mfma_small_pack_kernel(const __bf16* W0, const __bf16* W1, __bf16* packed) {
+    typedef MfsGeom<H> G;
+    const int total = 2 * G::NF * 64 * 8;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+        int r = idx;
+        const int j = r & 7; r >>= 3;
+        const int lane = r & 63; r >>= 6;
+        const int f = r % G::NF;
+        const int dir = r / G::NF;
+        const int g = f / (G::TPW * G::KSN), rem = f % (G::TPW * G::KSN);
+        const int tl = rem / G::KSN, ks = rem % G::KSN;
+        const int k = ks * 32 + 8 * (lane >> 4) + j;
+        const int unit = tl * 16 + (lane & 15);
+        const __bf16* W = dir ? W1 : W0;
+        packed[idx] = (k < H && unit < H) ? W[(size_t)k * 3 * H + g * H + unit] : (__bf16)0.0f;
+    }
+}
+
+template <int H>
+__global__ void __launch_bounds__(64 * MfsGeom<H>::WPB)
+gru_mfma_small_kernel(GruArgs a, const __bf16* packed) {
+    typedef MfsGeom<H> G;
+    constexpr int TPW = G::TPW, KSN = G::KSN, PITCH = G::PITCH;
+    typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int dir = blockIdx.y, seq0 = (blockIdx.x * G::WPB + wave) * 16;
+    if (seq0 >= a.n_seq) return;                                  // (no workgroup barrier below: a wave may leave)
+    __bf16* hb = reinterpret_cast<__bf16*>(smem) + (size_t)wave * 2 * 16 * PITCH;     // [16][PITCH], this wave's own
+    __bf16* rhb = hb + 16 * PITCH;
+    const int n = lane & 15, q = lane >> 4;
+    const int seq = min(seq0 + n, a.n_seq - 1);
+    const bool seq_ok = (seq0 + n) < a.n_seq;
+    const bf16x8v* pk = reinterpret_cast<const bf16x8v*>(packed) + (size_t)dir * G::NF * 64 + lane;
+    bf16x8v w[3][TPW][KSN];
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl)
+#pragma unroll
+            for (int ks = 0; ks < KSN; ++ks) w[g][tl][ks] = pk[(size_t)((g * TPW + tl) * KSN + ks) * 64];
+    for (int i = lane; i < 2 * 16 * PITCH; i += 64) hb[i] = (__bf16)0.0f;        // hb and rhb, padding columns included
+    float hreg[TPW][4];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hreg[tl][e] = 0.0f;
+
+    const int H3 = 3 * H;
+    const size_t xrow = 6 * (size_t)H;
+    const float* xbase = a.xproj + (size_t)seq * a.T * xrow + (size_t)dir * H3 + q * 4;
+    bool uok[TPW];                                                // this lane's 4 units of tile tl exist (H % 4 == 0)
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) uok[tl] = tl * 16 + q * 4 < H;
+    int t = dir ? a.T - 1 : 0;
+    const int dt = dir ? -1 : 1;
+    const f32x4m zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4m xr[TPW], xu[TPW], xc[TPW];
+#pragma unroll
+    for (int tl = 0; tl < TPW; ++tl) {
+        const float* xp = xbase + (size_t)t * xrow + tl * 16;
+        xr[tl] = uok[tl] ? *reinterpret_cast<const f32x4m*>(xp) : zero4;
+        xu[tl] = uok[tl] ? *reinterpret_cast<const f32x4m*>(xp + H) : zero4;
+        xc[tl] = uok[tl] ? *reinterpret_cast<const f32x4m*>(xp + 2 * H) : zero4;
+    }
+    const __bf16* hrow = hb + n * PITCH + 8 * q;
+    const __bf16* rrow = rhb + n * PITCH + 8 * q;
+    for (int step = 0; step < a.T; ++step, t += dt) {
+        const float* xn = xbase + (size_t)(step + 1 < a.T ? t + dt : t) * xrow;
+        bf16x8v bfr[KSN];
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8v*>(hrow + ks * 32);
+        f32x4m ar[TPW], au[TPW];
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+            ar[tl] = xr[tl];
+            au[tl] = xu[tl];
+            xr[tl] = uok[tl] ? *reinterpret_cast<const f32x4m*>(xn + tl * 16) : zero4;
+            xu[tl] = uok[tl] ? *reinterpret_cast<const f32x4m*>(xn + tl * 16 + H) : zero4;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+            for (int tl = 0; tl < TPW; ++tl) {
+                ar[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0][tl][ks], bfr[ks], ar[tl], 0, 0, 0);
+                au[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1][tl][ks], bfr[ks], au[tl], 0, 0, 0);
+            }
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+            bf16x4v o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (__bf16)(fast_sigmoid(ar[tl][e]) * hreg[tl][e]);
+            if (uok[tl]) *reinterpret_cast<bf16x4v*>(rhb + n * PITCH + tl * 16 + q * 4) = o;
+        }
+        // (same wave: the LDS writes above are ordered before the reads below)
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks) bfr[ks] = *reinterpret_cast<const bf16x8v*>(rrow + ks * 32);
+        f32x4m ac[TPW];
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+            ac[tl] = xc[tl];
+            xc[tl] = uok[tl] ? *reinterpret_cast<const f32x4m*>(xn + tl * 16 + 2 * H) : zero4;
+        }
+#pragma unroll
+        for (int ks = 0; ks < KSN; ++ks)
+#pragma unroll
+            for (int tl = 0; tl < TPW; ++tl)
+                ac[tl] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2][tl][ks], bfr[ks], ac[tl], 0, 0, 0);
+#pragma unroll
+        for (int tl = 0; tl < TPW; ++tl) {
+            bf16x4v o;
+            f32x4m hv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float u = fast_sigmoid(au[tl][e]);
+                const float c = fast_tanh(ac[tl][e]);
+                const float hn = u * hreg[tl][e] + (1.0f - u) * c;
+                hreg[tl][e] = hn;
+                hv[e] = hn;
+                o[e] = (__bf16)hn;
+            }
+            if (uok[tl]) {
+                *reinterpret_cast<bf16x4v*>(hb + n * PITCH + tl * 16 + q * 4) = o;
+                if (seq_ok) {
+                    const size_t oi = ((size_t)seq * a.T + t) * 2 * H + (size_t)dir * H + tl * 16 + q * 4;
+                    if (a.out_bf16) *reinterpret_cast<bf16x4v*>(reinterpret_cast<__bf16*>(a.out) + oi) = o;
+                    else *reinterpret_cast<f32x4m*>(reinterpret_cast<float*>(a.out) + oi) = hv;
+                }
+            }
+        }
+    }
+}
+
+template <int H>
+int launch_mfma_small(const GruArgs& a, void* ws, size_t ws_bytes, hipStream_t st) {
+    typedef MfsGeom<H> G;
+    const size_t need = 2 * (size_t)G::NF * 64 * 16;
+    if (ws == nullptr || ws_bytes < need)
+        return vc::set_error(VC_ERR_WORKSPACE, "vc_gru_bidir: workspace too small (%zu < %zu)", ws_bytes, need);
+    __bf16* packed = static_cast<__bf16*>(ws);
+    hipLaunchKernelGGL((gru_mfma_small_pack_kernel<H>), dim3(16), dim3(256), 0, st, static_cast<const __bf16*>(a.Wh[0]),
+                       static_cast<const __bf16*>(a.Wh[1]), packed);
+    const int groups = (a.n_seq + 15) / 16;
+    hipLaunchKernelGGL((gru_mfma_small_kernel<H>), dim3((groups + G::WPB - 1) / G::WPB, 2), dim3(64 * G::WPB), G::LDS, st, a,
+                       static_cast<const __bf16*>(packed));
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // Single-wave recurrence for small H (the encoder: H = 40): one 64-lane wave per (window,
 // direction), no LDS and no barriers.  Lane j owns hidden unit j: its three weight columns
 // (r_j, u_j, c_j: 3H f32 registers) and h_j.  h is broadcast to the wave one element at a time
@@ -960,6 +1134,7 @@ extern "C" {
 
 size_t vc_gru_workspace_bytes(int32_t H, int32_t w_dtype) {
     if (H <= 0) return 0;
+    if (H == 40 && w_dtype == VC_BF16) return 2 * (size_t)MfsGeom<40>::NF * 64 * 16;       // padded fragment order
     return 2 * (size_t)3 * H * H * (w_dtype == VC_F32 ? 4 : 2);
 }
 
@@ -998,6 +1173,11 @@ int vc_gru_bidir(const float* d_xproj, const void* d_Wh_fw, const void* d_Wh_bw,
                                                       : launch_mfma<128>(a, d_workspace, workspace_bytes, st);
     // (H = 128 runs 256 threads: four fat waves beat sixteen thin ones, the step is barrier-bound)
     if (w_dtype == VC_F32 && H == 128) return launch_resident<128, float, 1024>(a, d_workspace, workspace_bytes, st);
+    if (H == 40 && w_dtype == VC_BF16) {
+        // the shipped encoder in bf16: 16 sequences per wave on MFMA -- only with option gru_small_mfma = 1 (see the kernel's comment)
+        const int sm = vc::opt(vc::OPT_GRU_SMALL_MFMA);
+        if (sm == 1) return launch_mfma_small<40>(a, d_workspace, workspace_bytes, st);      // measured slower: off unless asked for
+    }
     if (H == 40) {                                      // the shipped encoder (hp/encoder_cfg_d.json)
         const dim3 gw((n_seq + GRU_WAVE_WPB - 1) / GRU_WAVE_WPB, 2);
         if (w_dtype == VC_F32) hipLaunchKernelGGL((gru_wave_kernel<40, float>), gw, dim3(64 * GRU_WAVE_WPB), 0, st, a);

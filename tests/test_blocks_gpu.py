@@ -410,6 +410,38 @@ def test_gru_mfma_recurrence(H, T, N):
     assert (y.float() - yv.float()).abs().max().item() < 2e-2          # the two kernels agree to bf16 rounding
 
 
+@pytest.mark.parametrize('T,N', [(60, 3), (40, 20), (25, 70)])
+def test_gru_small_mfma_recurrence(T, N):
+    """The encoder's recurrence (H = 40, bf16; /root/reference/modules.py:168-204) with 16 sequences per WAVE on MFMA
+    (csrc/vc_rnn.hip gru_mfma_small_kernel: weights padded to 48 x 64 in registers, wave-private LDS hand-off, no
+    barriers; a measured alternative, off by default, forced here) against the oracle, against the one-wave-per-sequence
+    kernel it replaces, partly filled groups of 16 included, and run-to-run identical with NaN-poisoned LDS."""
+    import modules
+    from conftest import poison_gpu_state
+    H = 40
+    rng = np.random.RandomState(T + N)
+    st = _store('bfloat16')
+    x = torch.from_numpy((0.7 * rng.standard_normal((N, T, H))).astype(np.float32))
+    xd = modules.convert(x.cuda(), st.dtype)
+    try:
+        with modules.variable_store(st), modules.variable_scope('g'):
+            _vc.set_option('gru_small_mfma', 1)
+            y = modules.gru(xd, num_units=H, bidirection=True)
+            poison_gpu_state()
+            y2 = modules.gru(xd, num_units=H, bidirection=True)
+            _vc.set_option('gru_small_mfma', 0)
+            yw = modules.gru(xd, num_units=H, bidirection=True)
+    finally:
+        _vc.set_option('gru_small_mfma', -1)
+    assert not torch.isnan(y.float()).any()
+    assert torch.equal(y, y2)
+    cast = lambda t: t.float().bfloat16().double()
+    w = {k: (cast(v.cpu()) if k.endswith('kernel') else v.cpu().double()) for k, v in st.vars.items()}
+    ref = mo.gru_bidirectional(cast(x), w, 'g/gru')
+    _close(y, ref, 3e-2, 'gru small mfma')
+    assert (y.float() - yw.float()).abs().max().item() < 2e-2          # the two kernels agree to bf16 rounding
+
+
 def test_softmax_argmax_exact_ties_and_padding():
     import modules
     rng = np.random.RandomState(1)

@@ -667,7 +667,7 @@ def test_encoder_train_step_matches_autograd(golden_dir):
         acc, mse = mo.encoder_metrics(lg.detach(), torch.from_numpy(target).double())
         loss.backward()
         got = out3.cpu().numpy()
-        assert abs(got[0] - float(loss)) < 1e-5 * max(1.0, float(loss)), (got, float(loss))
+        assert abs(got[0] - float(loss.detach())) < 1e-5 * max(1.0, float(loss.detach())), (got, float(loss.detach()))
         assert abs(got[1] - float(acc)) < 1e-6 + 1.0 / M and abs(got[2] - float(mse)) < 1e-6
         worst = ('', 0.0)
         for n in tr.names:
