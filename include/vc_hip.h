@@ -58,9 +58,8 @@ const char* vc_target_arch(void);
  *   "proj256_split"  0 = never split that projection's K over two workgroups per row tile (see d_workspace)
  *   "wgrad_xcd"      0 = weight-gradient tiles dealt round-robin to the XCDs
  *   "gru_mfma"       0 = VALU recurrence always, 1 = MFMA recurrence always (default: from 32 sequences up)
- *   "fe_fused"       the shipped front-end configuration as ONE launch (every frame transformed once; blocks wait for the
- *                    tile records of their own utterance): 1 = always, 0 = never (two launches: statistics pass, feature
- *                    pass); default: one launch while all its workgroups are resident at once (<= 1024 tiles of 14 frames)
+ *   "fe_fused"       0 = the shipped front-end configuration as two launches (statistics pass, feature pass) instead of ONE
+ *                    (every frame transformed once; blocks wait for the summary of their own utterance)
  *   "fe_fused_spin"  polls a block of the one-launch front-end waits for the other tiles of its utterance before it
  *                    computes their records itself (default 4000, ~4 ms); 0 = never wait (tests of that path)
  *   "gru_small_mfma" 1 = the encoder's H = 40 bf16 recurrence with 16 sequences per wave on MFMA instead of one wave per

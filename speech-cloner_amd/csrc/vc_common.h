@@ -39,7 +39,7 @@ enum Option {
     OPT_PROJ256_SPLIT,    // 0: never split that projection's K over two workgroups per row tile
     OPT_WGRAD_XCD,        // 0: weight-gradient tiles dealt round-robin instead of group-per-XCD
     OPT_GRU_MFMA,         // 0: VALU recurrence always, 1: MFMA recurrence always (default: from 32 sequences up)
-    OPT_FE_FUSED,         // shipped front-end configuration in one launch: 1 always, 0 never, default while all workgroups are co-resident
+    OPT_FE_FUSED,         // 0: the shipped front-end configuration as two launches (statistics pass + feature pass) instead of one
     OPT_FE_FUSED_SPIN,    // polls a block of the one-launch front-end waits for its utterance's tiles (default 4000 ~ 4 ms); 0: never wait
     OPT_GRU_SMALL_MFMA,   // 1: the encoder's H = 40 bf16 recurrence on the 16-sequence MFMA wave (measured slower; default: gru_wave_kernel)
     OPT_GRU_MFMA4,        // 1: the four-wave, all-weights-in-registers MFMA recurrence (measured slower; default: eight waves)

@@ -828,14 +828,10 @@ int vc_frontend_stages_f32(const vc_frontend_plan* plan, const float* d_wav, con
         f.fstride = vc_fe400_fused_stride(max_frames);
         f.fstats = reinterpret_cast<float*>(wsb + o_mel + o_rec);
         const bool room = o_rec + (size_t)batch * f.fstride * 4 <= total - o_mel && batch <= FE400_FUSED_MAX_BATCH;
-        // Chosen by itself only while every workgroup of the launch is resident at once (256 CUs x 4): a waiting block
-        // keeps its slot, so past one round of workgroups the second round starts behind the first one's waits and the
-        // form loses what the saved transform had won (tools/fe_fused_probe.py: 27.4 vs 30.3 us at 17 utterances of 4 s,
-        // 47.8 vs 47.3 at 32, 88.9 vs 77.8 at 64).  vc_set_option("fe_fused", 1 / 0) forces either.
-        const int fopt = vc::opt(vc::OPT_FE_FUSED);
-        const long fused_blocks = (long)batch * ((max_frames + 13) / 14);
-        const bool fused = room && (stage_mask & 6) == 6 && vc_fe400_fused_ok(max_frames) &&
-                           (fopt == 1 || (fopt != 0 && fused_blocks <= 1024));
+        // One launch unless switched off (vc_set_option("fe_fused", 0): two launches, statistics pass + feature pass) or an
+        // utterance is too long for it (vc_fe400_fused_ok).  Measured against the two launches with all rows stored: 23.6 vs
+        // 29.8 us at 16 utterances of 4 s, 40.2 vs 46.7 at 32, 70.9 vs 76.6 at 64 (tools/fe_fused_probe.py).
+        const bool fused = room && (stage_mask & 6) == 6 && vc_fe400_fused_ok(max_frames) && vc::opt(vc::OPT_FE_FUSED) != 0;
         const unsigned par = plan->fused_launches & 1;
         const size_t set_words = (size_t)vc_fe400_fused_count_bytes(FE400_FUSED_MAX_BATCH) / 4;
         f.fcount = plan->d_fcount + par * set_words;

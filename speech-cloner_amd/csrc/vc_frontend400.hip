@@ -507,9 +507,11 @@ fe400_kernel(Fe400Args a) {
 // delta from LDS and stores.  Blocks whose frames lie past `out_rows` only publish and leave.
 //
 // Hand-off (cdna_hip_programming.md Guideline 16, form R1): record words are write-through (sc1) stores, every storing
-// wave drains them (vmcnt(0)), a workgroup barrier, then ONE lane adds to the utterance's counter (agent scope); the
-// consumer polls that word relaxed from one lane and reads the records with sc1 loads only (they bypass this CU's L1:
-// nothing here can be stale; each utterance's record array is padded to whole 128-byte lines anyway).
+// wave drains them (vmcnt(0)), a workgroup barrier, then ONE lane adds to the utterance's counter (agent scope).  The tile
+// whose add completes the count reduces the utterance's records to one line (write-through, drained) and raises the
+// utterance's READY word; the consumers poll that word relaxed from one lane and read the line with sc1 loads only (they
+// bypass this CU's L1: nothing here can be stale; every utterance's records, its line, its counter and its READY word
+// sit on cache lines of their own).
 //
 // Forward progress without any assumption about dispatch order or residency: a publisher never waits, and a waiter
 // whose poll runs out (4 ms; an utterance's tiles normally arrive within microseconds of each other because workgroups
@@ -562,7 +564,7 @@ fe400_fused_kernel(Fe400Args a) {
     }
     if (own == 0) {                                     // the previous launch's counters, for the launch after this one
         for (int u = b + (int)gridDim.y * tid; u < FE400_FUSED_MAX_BATCH; u += (int)gridDim.y * NT)
-            a.fcount_other[(size_t)u * FCOUNT_PITCH] = 0u;
+            { a.fcount_other[(size_t)u * FCOUNT_PITCH] = 0u; a.fcount_other[(size_t)u * FCOUNT_PITCH + 32] = 0u; }
     }
     const int nt_b = (F + GO - 1) / GO;                 // tiles of this utterance that publish
     const bool has_out = fo_own < a.out_rows;
@@ -740,14 +742,39 @@ fe400_fused_kernel(Fe400Args a) {
             float* r8 = recs + (size_t)cur * 8;
             st_sc1(r8 + 0, pmax); st_sc1(r8 + 1, pmin); st_sc1(r8 + 2, mmax); st_sc1(r8 + 3, mmin); st_sc1(r8 + 4, asum);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (mode == 0) {
-                __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (mode == 0 && wv == 0) {
+            // Arrival (wave 0).  The LAST tile of the utterance to arrive reduces the records to one line and raises the
+            // utterance's READY word; everybody else polls that word and reads the one line (58 records gathered by
+            // every block cost 7 k cycles of a 52 k-cycle block life and most of the L2 traffic the polls compete with).
+            unsigned old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+            if (old == (unsigned)(nt_b - 1)) {
+                float r_pmx = NEG_INF, r_pmn = POS_INF, r_mmx = NEG_INF, r_mmn = POS_INF, r_as = 0.0f;
+                for (int t = lane; t < nt_b; t += 64) {
+                    const float* q8 = recs + (size_t)t * 8;
+                    r_pmx = fmaxf(r_pmx, ld_sc1(q8 + 0)); r_pmn = fminf(r_pmn, ld_sc1(q8 + 1));
+                    r_mmx = fmaxf(r_mmx, ld_sc1(q8 + 2)); r_mmn = fminf(r_mmn, ld_sc1(q8 + 3));
+                    r_as += ld_sc1(q8 + 4);
+                }
+                r_pmx = vc::wave_max(r_pmx); r_pmn = vc::wave_min(r_pmn);
+                r_mmx = vc::wave_max(r_mmx); r_mmn = vc::wave_min(r_mmn);
+                r_as = vc::wave_sum(r_as);
+                if (lane == 0) {
+                    float* s8 = recs + a.fstride - 32;
+                    st_sc1(s8 + 0, r_pmx); st_sc1(s8 + 1, r_pmn); st_sc1(s8 + 2, r_mmx); st_sc1(s8 + 3, r_mmn); st_sc1(s8 + 4, r_as);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_store(cnt + 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            if (lane == 0) {
                 int ok = 1;
                 if (has_out) {
                     ok = 0;
                     for (int spins = 0; spins < a.spin_limit; ++spins) {
-                        if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)nt_b) { ok = 1; break; }
-                        __builtin_amdgcn_s_sleep(24);
+                        if (__hip_atomic_load(cnt + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { ok = 1; break; }
+                        __builtin_amdgcn_s_sleep(16);
                     }
                 }
                 reinterpret_cast<int*>(sc)[40] = ok;
@@ -773,20 +800,29 @@ fe400_fused_kernel(Fe400Args a) {
     asm volatile("" : "+v"(tid_c));
     const int mm_c = tid_c % NM, mg_c = tid_c / NM;
     if (tid_c < 64) {
-        float r_pmx = NEG_INF, r_pmn = POS_INF, r_mmx = NEG_INF, r_mmn = POS_INF, r_as = 0.0f, r_v0 = 1.0f, r_v1 = 1.0f;
-        for (int t = tid_c; t < nt_b; t += 64) {
-            const float* r8 = recs + (size_t)t * 8;
-            r_pmx = fmaxf(r_pmx, ld_sc1(r8 + 0)); r_pmn = fminf(r_pmn, ld_sc1(r8 + 1));
-            r_mmx = fmaxf(r_mmx, ld_sc1(r8 + 2)); r_mmn = fminf(r_mmn, ld_sc1(r8 + 3));
-            r_as += ld_sc1(r8 + 4);
-        }
+        float r_v0 = 1.0f, r_v1 = 1.0f;
         if (a.first_mfcc && tid_c < NH) {
             r_v0 = ld_sc1(a.mel0 + (size_t)b * NM + tid_c);
             r_v1 = ld_sc1(a.mel0 + (size_t)b * NM + NM - 1 - tid_c);
         }
-        const float pmx = vc::wave_max(r_pmx), pmn = vc::wave_min(r_pmn);
-        const float mmx = vc::wave_max(r_mmx), mmn = vc::wave_min(r_mmn);
-        const float as = vc::wave_sum(r_as);
+        float pmx, pmn, mmx, mmn, as;
+        if (mode == 2) {
+            // this block computed the records itself (its poll ran out): the same reduction, in the same order, as the
+            // last arriver's
+            float r_pmx = NEG_INF, r_pmn = POS_INF, r_mmx = NEG_INF, r_mmn = POS_INF, r_as = 0.0f;
+            for (int t = tid_c; t < nt_b; t += 64) {
+                const float* r8 = recs + (size_t)t * 8;
+                r_pmx = fmaxf(r_pmx, ld_sc1(r8 + 0)); r_pmn = fminf(r_pmn, ld_sc1(r8 + 1));
+                r_mmx = fmaxf(r_mmx, ld_sc1(r8 + 2)); r_mmn = fminf(r_mmn, ld_sc1(r8 + 3));
+                r_as += ld_sc1(r8 + 4);
+            }
+            pmx = vc::wave_max(r_pmx); pmn = vc::wave_min(r_pmn);
+            mmx = vc::wave_max(r_mmx); mmn = vc::wave_min(r_mmn);
+            as = vc::wave_sum(r_as);
+        } else {
+            const float* s8 = recs + a.fstride - 32;     // the utterance's line, written by its last arriver
+            pmx = ld_sc1(s8 + 0); pmn = ld_sc1(s8 + 1); mmx = ld_sc1(s8 + 2); mmn = ld_sc1(s8 + 3); as = ld_sc1(s8 + 4);
+        }
         float offp = 0.0f;
         if (a.amp_norm != 1.0f) offp = 2.0f * DB10 * __log2f(a.amp_norm / (as / (float)L));
         const float offm = 2.0f * offp;
@@ -927,7 +963,7 @@ fe400_fused_kernel(Fe400Args a) {
 }  // namespace
 
 int vc_fe400_fused_count_bytes(int batch) { return batch * FCOUNT_PITCH * 4; }
-int vc_fe400_fused_stride(int max_frames) { return (((max_frames + GO - 1) / GO) * 8 + 31) & ~31; }
+int vc_fe400_fused_stride(int max_frames) { return ((((max_frames + GO - 1) / GO) * 8 + 31) & ~31) + 32; }       // + the utterance's summary line
 // (utterances up to ~36 s; longer ones would keep early tiles waiting for tiles many rounds of workgroups away)
 bool vc_fe400_fused_ok(int max_frames) { return (max_frames + GO - 1) / GO <= 512; }
 

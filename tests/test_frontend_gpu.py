@@ -158,10 +158,9 @@ def test_stored_rows_can_be_fewer_than_the_frames():
 
 
 def test_one_launch_form_equals_two_pass_and_never_depends_on_waiting():
-    """The shipped configuration can run as ONE launch (csrc/vc_frontend400.hip, fe400_fused_kernel: every frame transformed
-    once; a block publishes its tile record, waits for the tiles of its own utterance, finishes from LDS) -- chosen by
-    itself for launches whose workgroups are all resident at once, forced here (fe_fused = 1) also for the benchmark's
-    batch, which takes two rounds of workgroups.
+    """The shipped configuration runs as ONE launch (csrc/vc_frontend400.hip, fe400_fused_kernel: every frame transformed
+    once; a block publishes its tile record, the utterance's last arriver reduces the records to one line, every block
+    waits for that line and finishes from LDS).
       * against the two-launch form (option fe_fused = 0) the extremes are identical and sum|x| differs only in
         summation order: features equal to 2e-6, and both within the front-end tolerances of the oracle;
       * a block whose poll runs out computes the utterance's records itself: with fe_fused_spin = 0 EVERY block takes that

@@ -10,7 +10,8 @@ for B in (4, 8, 16, 17, 24, 32, 64):
     for R in (801, 14):
         out = audio_lib.calc_MFCC_input_batch(wav, None, out_frames=R, **bench.FE_KW)
         f = lambda: audio_lib.calc_MFCC_input_batch(wav, None, out=out, out_frames=R, **bench.FE_KW)
-        t1 = bench.time_events(f, 50)
+        with _vc.options(fe_fused=1):
+            t1 = bench.time_events(f, 50)
         with _vc.options(fe_fused=0):
             t2 = bench.time_events(f, 50)
         print('B=%2d rows=%3d  one launch %.4f ms   two launches %.4f ms' % (B, R, t1, t2), flush=True)

@@ -31,7 +31,8 @@ passes = ((6, (mf + 13) // 14, names3),) if (len(sys.argv) > 1 and sys.argv[1] =
 for mask, nblk, names in passes:
     for _ in range(3):
         if mask == 6:
-            out = audio_lib.calc_MFCC_input_batch(wav, None, out=out, **kw)
+            with _vc.options(fe_fused=1):
+                out = audio_lib.calc_MFCC_input_batch(wav, None, out=out, **kw)
         else:
             with _vc.options(fe_fused=0):
                 out = audio_lib.calc_MFCC_input_batch(wav, None, out=out, stage_mask=mask, **kw)
