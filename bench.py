@@ -262,13 +262,14 @@ class _Pipeline:
         torch.cuda.synchronize()
 
     def timed(self, steps, warmup, world):
-        """Throughput mode (several batches in flight): a launch costs its CU time, not its makespan, so the k = 3
-        projection's K split -- twice the workgroups to fill an otherwise idle chip, -43 % for a single batch -- is
-        switched off here (measured in this loop: split +0.8 % ms/step, profiles/r03/ab_proj_split.log); the
-        single-stream figures of the same line run with the library's default (split)."""
+        """Throughput mode (several batches in flight): a launch costs its CU time, not its makespan.  The two kernels that
+        fill an idle chip at the price of extra workgroup time -- the k = 3 projection's K split (+0.8 % ms/step here) and
+        the one-launch front-end, whose blocks wait for their utterance (+5.5 %) -- are switched off for this loop
+        (`_vc.throughput_mode()`; profiles/r03/ab_step_latency_kernels.log); the single-stream figures of the same line
+        run with the library's defaults."""
         import _vc
         if self.streams is not None:
-            with _vc.options(proj256_split=0):
+            with _vc.throughput_mode():
                 return self._timed(steps, warmup, world)
         return self._timed(steps, warmup, world)
 

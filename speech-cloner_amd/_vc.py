@@ -232,6 +232,20 @@ def options(**kw):
             set_option(k, v)
 
 
+# Two kernels fill an otherwise idle chip at the price of extra workgroup time: the k = 3 projection's K split over two
+# workgroups per row tile (-43 % for that launch alone, +0.8 % per step when ten batches are in flight) and the
+# front-end's one-launch form, whose blocks WAIT for their utterance (-14 % alone, +5.5 % per pipelined step: a waiting
+# block keeps its CU from the register-filling MFMA launches of the other streams).  The library's defaults serve a
+# caller with one batch at a time (the reference's test.py); a caller that keeps several batches in flight on several
+# streams runs its loop under this context (bench.py's throughput loop does).
+THROUGHPUT_OPTIONS = {'proj256_split': 0, 'fe_fused': 0}
+
+
+def throughput_mode():
+    """with _vc.throughput_mode(): ...  -- the option set for callers that keep several batches in flight."""
+    return options(**THROUGHPUT_OPTIONS)
+
+
 def check(rc):
     if rc != VC_OK:
         msg = lib().vc_last_error()
