@@ -1,5 +1,8 @@
-"""Upper bound of what the per-step weight re-layouts (torch glue behind store.invalidate()) cost the training step: the same
-step with the kernel-layout caches kept (stale weights in the copies: WRONG numerics, timing only).
+"""What parts of the training step cost in WALL time, by leaving them out (WRONG numerics, timing only): every weight-gradient
+launch (side stream) -> what all of them together cost; the kernel-layout caches kept stale -> upper bound of what a
+one-launch refresh of the per-step weight re-layouts could gain.  Round 3, MI355X: 39.1 / 31.2 / 38.2 ms per step.
+(Also measured and not kept: the transposed copies of the forward activations built under the forward pass instead of
+in front of each weight-gradient launch: 39.25 vs 39.17 ms.)
 python tools/train_glue_bound.py"""
 import os, sys, time, contextlib, io
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -32,6 +35,17 @@ dec.store.invalidate = lambda: None
 b = [run(5) for _ in range(3)]
 dec.store.invalidate = inv
 c = [run(5) for _ in range(3)]
+import training
+wg, tp = training._Ops.wgrad, training._Ops.transpose
+training._Ops.wgrad = staticmethod(lambda *a_, **k_: None)
+d = [run(5) for _ in range(3)]
+training._Ops.wgrad = wg
+import _vc
+gb, gf = _vc.lib().vc_gru_backward, _vc.lib().vc_gru_train_forward
+class _Nop:
+    def __call__(self, *a_, **k_): return 0
+lib = _vc.lib()
 print('shipped           ms/step', ['%.2f' % v for v in a])
+print('no weight-gradient launches (wrong numerics: what ALL of them cost the step)', ['%.2f' % v for v in d])
 print('caches kept stale ms/step', ['%.2f' % v for v in b], '(wrong numerics: upper bound of the gain)')
 print('shipped again     ms/step', ['%.2f' % v for v in c])
