@@ -185,3 +185,36 @@ def test_a_library_of_another_abi_version_is_refused(tmp_path):
     r = subprocess.run([sys.executable, '-c', code], env=dict(os.environ, VC_LIB_PATH=str(so)), capture_output=True,
                        text=True, timeout=300)
     assert r.returncode == 0 and 'REFUSED' in r.stdout and 'ABI version 1' in r.stdout, r.stdout + r.stderr
+
+
+def test_workspace_queries_are_host_only():
+    """vc_conv_gemm_workspace_bytes / vc_gru_workspace_bytes make no GPU call: the split-K scratch of the 256-channel long-K
+    projection (include/vc_hip.h, vc_gemm_desc.d_workspace) is asked for exactly where the launch would split -- <= 128
+    row tiles of 256 frames, K = taps x Cin >= 4096, bf16 -- and not at all with proj256_split = 0 or for other launches."""
+    import _vc
+    lib = _vc.lib()
+
+    def desc(M, cin, taps, N=256, dtype=_vc.VC_BF16):
+        d = _vc.GemmDesc()
+        d.dtype, d.mode, d.d_X = dtype, _vc.GEMM_PLAIN, 4096            # (any non-NULL, 16-byte aligned address: never dereferenced)
+        d.M, d.T, d.Cin, d.ldx, d.N, d.n_groups = M, 400, cin, cin, N, 1
+        g = d.groups[0]
+        g.d_Bt, g.K, g.taps, g.pad_l, g.c_off = 4096, taps * cin, taps, (taps - 1) // 2, 0
+        d.act, d.d_C, d.ldc = _vc.ACT_RELU, 4096, N
+        return d
+
+    q = lambda d: lib.vc_conv_gemm_workspace_bytes(ctypes.byref(d))
+    ntm = 100                                                            # 64 windows x 400 frames / 256
+    assert q(desc(25600, 4096, 3)) == ((ntm * 8 + 255) // 256) * 256 + ntm * 262144
+    assert q(desc(51200, 4096, 3)) == 0                                  # 200 row tiles fill the chip by themselves
+    assert q(desc(25600, 4096, 3, N=128)) == 0 and q(desc(25600, 256, 3)) == 0 and q(desc(25600, 4096, 3, dtype=_vc.VC_F32)) == 0
+    with _vc.options(proj256_split=0):
+        assert q(desc(25600, 4096, 3)) == 0
+    with _vc.options(proj256=0):
+        assert q(desc(25600, 4096, 3)) == 0
+    assert lib.vc_gru_workspace_bytes(256, _vc.VC_BF16) == 2 * 3 * 256 * 256 * 2
+    assert lib.vc_gru_workspace_bytes(40, _vc.VC_BF16) >= 2 * 3 * 40 * 40 * 2
+    assert _vc.THROUGHPUT_OPTIONS == {'proj256_split': 0, 'fe_fused': 0}
+    with _vc.throughput_mode():
+        assert _vc.get_option('fe_fused') == 0 and _vc.get_option('proj256_split') == 0
+    assert _vc.get_option('fe_fused') == -1
