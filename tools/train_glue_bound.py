@@ -36,15 +36,10 @@ b = [run(5) for _ in range(3)]
 dec.store.invalidate = inv
 c = [run(5) for _ in range(3)]
 import training
-wg, tp = training._Ops.wgrad, training._Ops.transpose
+wg = training._Ops.wgrad
 training._Ops.wgrad = staticmethod(lambda *a_, **k_: None)
 d = [run(5) for _ in range(3)]
 training._Ops.wgrad = wg
-import _vc
-gb, gf = _vc.lib().vc_gru_backward, _vc.lib().vc_gru_train_forward
-class _Nop:
-    def __call__(self, *a_, **k_): return 0
-lib = _vc.lib()
 print('shipped           ms/step', ['%.2f' % v for v in a])
 print('no weight-gradient launches (wrong numerics: what ALL of them cost the step)', ['%.2f' % v for v in d])
 print('caches kept stale ms/step', ['%.2f' % v for v in b], '(wrong numerics: upper bound of the gain)')
