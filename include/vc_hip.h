@@ -38,8 +38,9 @@ extern "C" {
 /* 2: vc_frontend_f32 / vc_frontend_stages_f32 take out_rows, vc_transpose_pad takes slack_row, vc_gemm_desc has
  *    sum_groups.  Bump on EVERY change of an exported signature or struct layout: the Python binding (_vc.py) refuses
  *    to load a library whose vc_version() differs from its own constant.
- * 3: vc_gemm_desc ends with d_workspace / workspace_bytes (vc_conv_gemm_workspace_bytes); vc_bn_post_routing added. */
-#define VC_ABI_VERSION 3
+ * 3: vc_gemm_desc ends with d_workspace / workspace_bytes (vc_conv_gemm_workspace_bytes); vc_bn_post_routing added.
+ * 4: vc_split16 / vc_weights16 / vc_gemm16 (training convolutions on split-float16 operands). */
+#define VC_ABI_VERSION 4
 
 int vc_version(void);
 const char* vc_last_error(void);
@@ -70,6 +71,8 @@ const char* vc_target_arch(void);
  *   "gru_train_resident" 0 = the float32 training recurrences stream all their weights from L2 every step (default:
  *                    128 units: all of them in registers, forward and backward; 256 units: half, forward)
  *   "cbhg_front_mi"  4 = 128-row blocks in the fused encoder front
+ *   "gemm16_split"   vc_gemm16, single-pair launches: ways K is split over workgroups (1..8) + 16 * block map (0 = the splits
+ *                    of a row tile on one XCD, 1 = one K range per XCD: ways must divide 8); default: chosen from the shape
  * All alternatives compute the same function (tests compare them).  Three more names, "ablate_bank256",
  * "ablate_bank256_only" and "ablate_cbhg_front", skip parts of a kernel for timing and give WRONG results: they
  * exist only in a library built with -DVC_ABLATE (tools/build_ablate.sh; vc_ablate_build() returns 1 there) and
@@ -328,6 +331,67 @@ int vc_conv_wgrad(const vc_wgrad_desc* desc, void* stream);
 int vc_transpose_pad(const float* d_X, int32_t M, int32_t C, int32_t ld, int32_t T, const float* d_scale,
                      const float* d_shift, int32_t relu, int32_t pool, int32_t row_shift, float* d_XT,
                      int32_t ldt, int32_t pad, int32_t slack_row, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Training convolutions on split-float16 operands ("f16x3"; csrc/vc_gemm16.hip).  The reference trains in float32
+ * (/root/reference/decoder.py:185-263); gfx950's f32-input MFMA runs at 1/16 of the 16-bit rate.  x * s (s a power of
+ * two) splits exactly into float16 hi + lo + r, |r| <= 2^-22 |x s|, and hi*hi + hi*lo + lo*hi summed in float32
+ * reproduces the float32 product to 2^-22: the error of the result against float64 equals a float32 GEMM's (tests).
+ * ------------------------------------------------------------------------------------------ */
+/* X [M, C] float32 (row stride ldx) -> d_out16 [M, 2C] float16 = [hi plane | lo plane] of pro(X)[m] * s_w, and
+ * d_row_scale[m] = 1 / s_w, s_w the power of two that puts the largest magnitude of the row's WINDOW (T rows) in
+ * [2^14, 2^15) (1 for an all-zero window): the taps of a convolution stay inside a window, whose rows must share
+ * their scale.  d_row_scale holds M + M / T floats: the tail is scratch.  pro = optional per-channel affine (d_scale /
+ * d_shift), relu, max-pool(2, 1, same) along time inside each window -- the operand prologue of vc_conv_gemm.
+ * C: a multiple of 64 up to 4096.  Two passes over X (window maxima, then the split). */
+int vc_split16(const float* d_X, int32_t M, int32_t C, int32_t ldx, int32_t T, const float* d_scale, const float* d_shift,
+               int32_t relu, int32_t pool, void* d_out16, float* d_row_scale, void* stream);
+/* One item of vc_weights16: a TF-layout float32 kernel src [k][cin][cout] -> float16 [hi | lo] operand rows at dst.
+ * mode 0 (forward operand):       row o (cout rows), column base + j * tap_stride + plane * plane_stride + c
+ * mode 1 (data-gradient operand): row c (cin rows),  column base + (k - 1 - j) * tap_stride + plane * plane_stride + o
+ * row_len = elements per dst row.  Items of one `group` share ONE power-of-two scale (their largest magnitude ->
+ * [2^14, 2^15)); 1 / scale is written to scale_dst[0 .. scale_n) (the GEMM's per-channel d_col_scale). */
+typedef struct vc_w16_item {
+    const float* src;
+    void* dst;
+    float* scale_dst;
+    int32_t k, cin, cout, mode;
+    int32_t row_len, tap_stride, plane_stride, base;
+    int32_t group, scale_n;
+} vc_w16_item;
+/* d_items: n_items items in DEVICE memory; d_gmax: n_groups uint32 of scratch.  Three launches, no host sync. */
+int vc_weights16(const vc_w16_item* d_items, int32_t n_items, uint32_t* d_gmax, int32_t n_groups, void* stream);
+/* C[m, c_off + n] (+)= ( sum over taps j, channels c of  X[m + j - pad_l, c] * W[n][j][c] ) * row_scale[m] * col_scale[ch]
+ *                     + col_shift[ch],   X and W the float32 values vc_split16 / vc_weights16 split, SAME padding per
+ * window of T rows like vc_conv_gemm.  A PAIR is two 128-column filters over the same input: widths (taps0, taps0 +
+ * extra) with a common pad_l (a filter-bank pair 2p+1 / 2p+2, /root/reference/modules.py:144-166), or the two halves
+ * of one 256-column filter (extra 0).  d_Bt0 / d_Bt1: [128][taps * 2C] float16, per tap [hi plane (C) | lo plane (C)].
+ * ragged != 0 is the filter bank's DATA gradient (tf.gradients through modules.py:144-166): X = dZ [M, C = 128 * K],
+ * bank k = 1..K contributes its 128 channels with k taps and left padding k / 2; rows of d_Bt*: [plane][bank k][tap]
+ * [128] (vc_w16_item mode 1 with tap_stride 128, plane_stride 128 * K (K + 1) / 2, base 128 * k (k - 1) / 2).
+ * A single-pair launch whose row tiles would not fill the chip splits K over up to 8 workgroups per row tile when
+ * given vc_gemm16_workspace_bytes() of workspace (partial sums added in a fixed order: bit-identical run to run). */
+typedef struct vc_gemm16_pair {
+    const void* d_Bt0;
+    const void* d_Bt1;
+    int32_t taps0, extra, pad_l, c_off0, c_off1;
+} vc_gemm16_pair;
+typedef struct vc_gemm16_desc {
+    const void* d_X16;          /* [M, ldx >= 2C] float16 from vc_split16 */
+    const float* d_row_scale;   /* [M] or NULL */
+    int32_t M, T, C, ldx;
+    int32_t n_pairs, ragged;
+    vc_gemm16_pair pairs[16];
+    const float* d_col_scale;   /* per output column, or NULL */
+    const float* d_col_shift;
+    float* d_C;
+    int32_t ldc;
+    int32_t accumulate;         /* != 0: add to the contents of d_C */
+    void* d_workspace;          /* 256-byte aligned, or NULL */
+    size_t workspace_bytes;
+} vc_gemm16_desc;
+size_t vc_gemm16_workspace_bytes(int32_t M, int32_t C, int32_t n_pairs);
+int vc_gemm16(const vc_gemm16_desc* desc, void* stream);
 
 /* Train-mode FusedBatchNorm bookkeeping (modules.py:77-84, is_training): batch mean / biased
  * variance of X [M, C] -> scale/shift (consumed by the next launch's prologue or vc_affine_act),

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('VC_LIB_PATH', os.path.join(_HERE, 'libvc_hip.so'))   # override: kernel A/B experiments
 
 VC_OK = 0
-VC_ABI_VERSION = 3      # include/vc_hip.h: VC_ABI_VERSION -- lib() refuses a library that reports another one
+VC_ABI_VERSION = 4      # include/vc_hip.h: VC_ABI_VERSION -- lib() refuses a library that reports another one
 
 
 class VCError(RuntimeError):
@@ -84,6 +84,27 @@ class LayoutItem(C.Structure):
                 ('mode', C.c_int32)]
 
 
+class W16Item(C.Structure):
+    """struct vc_w16_item (include/vc_hip.h)."""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('scale_dst', C.c_void_p), ('k', C.c_int32), ('cin', C.c_int32),
+                ('cout', C.c_int32), ('mode', C.c_int32), ('row_len', C.c_int32), ('tap_stride', C.c_int32),
+                ('plane_stride', C.c_int32), ('base', C.c_int32), ('group', C.c_int32), ('scale_n', C.c_int32)]
+
+
+class Gemm16Pair(C.Structure):
+    """struct vc_gemm16_pair (include/vc_hip.h)."""
+    _fields_ = [('d_Bt0', C.c_void_p), ('d_Bt1', C.c_void_p), ('taps0', C.c_int32), ('extra', C.c_int32),
+                ('pad_l', C.c_int32), ('c_off0', C.c_int32), ('c_off1', C.c_int32)]
+
+
+class Gemm16Desc(C.Structure):
+    """struct vc_gemm16_desc (include/vc_hip.h)."""
+    _fields_ = [('d_X16', C.c_void_p), ('d_row_scale', C.c_void_p), ('M', C.c_int32), ('T', C.c_int32), ('C', C.c_int32),
+                ('ldx', C.c_int32), ('n_pairs', C.c_int32), ('ragged', C.c_int32), ('pairs', Gemm16Pair * 16),
+                ('d_col_scale', C.c_void_p), ('d_col_shift', C.c_void_p), ('d_C', C.c_void_p), ('ldc', C.c_int32),
+                ('accumulate', C.c_int32), ('d_workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+
+
 class WgradGroup(C.Structure):
     """struct vc_wgrad_group (include/vc_hip.h)."""
     _fields_ = [('d_dYT', C.c_void_p), ('d_dW', C.c_void_p), ('N', C.c_int32), ('taps', C.c_int32),
@@ -147,6 +168,10 @@ _SIGS = {
     'vc_col_sum': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P]),
     'vc_fill': (C.c_int, [_P, C.c_float, C.c_size_t, _P]),
     'vc_weight_layouts': (C.c_int, [_P, C.c_int32, _P]),
+    'vc_split16': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
+    'vc_weights16': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
+    'vc_gemm16_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    'vc_gemm16': (C.c_int, [C.POINTER(Gemm16Desc), _P]),
     'vc_axpby': (C.c_int, [_P, C.c_int32, C.c_float, _P, C.c_int32, C.c_float, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     'vc_mse_loss': (C.c_int, [_P, _P, C.c_size_t, C.c_float, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     'vc_softmax_ce': (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P]),

@@ -19,6 +19,7 @@ import math
 import numpy as np
 
 import _vc
+import gemm16
 import modules
 from modules import BN_DECAY, BN_EPS, BANK_FILTERS, gemm_launch
 
@@ -178,6 +179,11 @@ class StageTrainer:
         self.overlap_allreduce = True                # False: one blocking all-reduce in apply_gradients (tests)
         self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
         self.export_routing = False                  # True: keep every relu / max-pool decision of the step (parity tests)
+        # The big convolutions (filter bank, post-bank projection, and their data gradients) as three float16 MFMA products
+        # of exactly split float32 operands (gemm16.py; float32 accuracy, 2-3x the f32-MFMA rate).  'train_f16x3': false
+        # in the configuration keeps every GEMM on the f32-input MFMA kernels.
+        self.f16x3 = bool(c.get('train_f16x3', True))
+        self._g16 = {}
         self.routing = {}
 
     def load_slots(self, ckpt):
@@ -222,6 +228,31 @@ class StageTrainer:
             out[n] = (self.m[off:off + k].view(shape), self.v[off:off + k].view(shape))
         return out
 
+    # ---------------------------------------------------------------- split-float16 operand plans
+    def _g16_plan(self, s, H, K, M, T_):
+        """Operands of the stage's convolutions for vc_gemm16, or None where the shapes do not fit its tiles (then the
+        f32-MFMA kernels take them).  The float16 copies follow the weights: rewritten (one vc_weights16 call per stage)
+        whenever the store's version moved -- after every Adam step, after a restore."""
+        if not self.f16x3 or K % 2 or K > 32 or H % 64 or M % T_ or modules.BANK_FILTERS != 128:
+            return None
+        pl = self._g16.get(s)
+        if pl is None:
+            b = s + '/CBHG/conv1d_banks'
+            kern = [self.w(b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k)) + '/conv1d/kernel') for k in range(1, K + 1)]
+            W1 = self.w(s + '/CBHG/conv1d_1/conv1d/kernel')                    # [3, 128 K, H]
+            w16 = gemm16.Weights16(self.store.device)
+            pl = {'w16': w16, 'version': None}
+            pl['bank_fwd'] = gemm16.bank_forward_operands(w16, kern, H)
+            pl['p1_dgrad'] = gemm16.conv_dgrad_operands(w16, W1)
+            if H == 256:                                                        # 256 output columns = one pair
+                pl['p1_fwd'] = gemm16.conv_forward_operands(w16, W1)
+                pl['bank_dgrad'] = gemm16.bank_dgrad_operands(w16, kern, H)
+            self._g16[s] = pl
+        if pl['version'] != self.store.version:
+            pl['w16'].refresh()
+            pl['version'] = self.store.version
+        return pl
+
     # ---------------------------------------------------------------- one stage forward
     def _stage_forward(self, s, X0, cin0, E, K, n_hw, n_out, seed_base):
         torch = _torch()
@@ -264,7 +295,14 @@ class StageTrainer:
             sub = b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k))
             groups.append((modules._prep_conv(st, sub, k, H, BANK_FILTERS), k * H, k, (k - 1) // 2, BANK_FILTERS * (k - 1)))
         Zb = torch.empty((M, CB), dtype=torch.float32, device=dev)
-        gemm_launch(D2, M, T_, H, H, BANK_FILTERS, groups, Zb, CB, f32, out_f32=True)
+        g16 = self._g16_plan(s, H, K, M, T_)
+        sv['g16'] = g16
+        if g16 is not None:
+            d16, drs = gemm16.split16(D2, M, H, H, T_)
+            gemm16.gemm16(d16, drs, M, T_, H, g16['bank_fwd'][0], Zb, CB, col_scale=g16['bank_fwd'][1])
+            del d16, drs
+        else:
+            gemm_launch(D2, M, T_, H, H, BANK_FILTERS, groups, Zb, CB, f32, out_f32=True)
         sb = _Ops.bn_stats(Zb, M, CB, self.w(b + '/bn/gamma'), self.w(b + '/bn/beta'),
                            self.w(b + '/bn/moving_mean'), self.w(b + '/bn/moving_variance'))
         if self.export_routing:
@@ -277,8 +315,13 @@ class StageTrainer:
         # conv1d_1 on pool(relu(bn(Zb))) -- normalisation, relu and pool in the operand prologue
         p1 = s + '/CBHG/conv1d_1'
         Q1 = torch.empty((M, H), dtype=torch.float32, device=dev)
-        gemm_launch(Zb, M, T_, CB, CB, H, [(modules._prep_conv(st, p1, 3, CB, H), 3 * CB, 3, 1, 0)], Q1, H, f32,
-                    pro_scale=sb[0], pro_shift=sb[1], pro_relu=1, pro_pool=1, out_f32=True)
+        if g16 is not None and 'p1_fwd' in g16:
+            z16, zrs = gemm16.split16(Zb, M, CB, CB, T_, scale=sb[0], shift=sb[1], relu=1, pool=1)
+            gemm16.gemm16(z16, zrs, M, T_, CB, g16['p1_fwd'][0], Q1, H, col_scale=g16['p1_fwd'][1])
+            del z16, zrs
+        else:
+            gemm_launch(Zb, M, T_, CB, CB, H, [(modules._prep_conv(st, p1, 3, CB, H), 3 * CB, 3, 1, 0)], Q1, H, f32,
+                        pro_scale=sb[0], pro_shift=sb[1], pro_relu=1, pro_pool=1, out_f32=True)
         s1 = _Ops.bn_stats(Q1, M, H, self.w(p1 + '/gamma'), self.w(p1 + '/beta'), self.w(p1 + '/moving_mean'),
                            self.w(p1 + '/moving_variance'))
         if self.export_routing:                    # vc_bn_backward mode 1: bn(Q1) > 0 (bit 0 of the same export)
@@ -529,7 +572,13 @@ class StageTrainer:
         _Ops.wgrad(PT, ldpt, CB, M, T_, dQ1T, ldq1, [(0, H, 3, -1, self.g(p1 + '/conv1d/kernel'), H)])
         del PT, dQ1T
         dP = torch.empty((M, CB), dtype=torch.float32, device=dev)
-        gemm_launch(dQ1, M, T_, H, H, CB, [(self._dgrad_conv_weight(W1c), 3 * H, 3, 1, 0)], dP, CB, f32, out_f32=True)
+        g16 = sv.get('g16')
+        if g16 is not None:
+            q16, qrs = gemm16.split16(dQ1, M, H, H, T_)
+            gemm16.gemm16(q16, qrs, M, T_, H, g16['p1_dgrad'][0], dP, CB, col_scale=g16['p1_dgrad'][1])
+            del q16, qrs
+        else:
+            gemm_launch(dQ1, M, T_, H, H, CB, [(self._dgrad_conv_weight(W1c), 3 * H, 3, 1, 0)], dP, CB, f32, out_f32=True)
         b = s + '/CBHG/conv1d_banks'
         dZb = _Ops.bn_backward(dP, sv['Zb'], M, CB, T_, self.w(b + '/bn/gamma'), sv['sb'], 2,
                                self.g(b + '/bn/gamma'), self.g(b + '/bn/beta'))
@@ -546,11 +595,20 @@ class StageTrainer:
         # data gradient of the banks: sum over k of conv(dZb[:, bank k], W_k^T flipped) + the residual path -- ONE launch
         # whose groups accumulate in the same tile (vc_gemm_desc.sum_groups), not K short-K launches chained through dD2
         grp = []
-        for k in range(1, K + 1):
-            sub = b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k))
-            Wk = self.w(sub + '/conv1d/kernel')                                      # [k, H, 128]
-            grp.append((self._dgrad_conv_weight(Wk), k * BANK_FILTERS, k, k - 1 - (k - 1) // 2, BANK_FILTERS * (k - 1)))
-        if M >= 128 and BANK_FILTERS % 32 == 0:
+        if g16 is not None and 'bank_dgrad' in g16:
+            # one launch walking bank after bank (its own taps and padding each) into the same accumulators, K split over
+            # workgroups in a fixed order; dD2 starts as the residual path's gradient
+            z16, zrs = gemm16.split16(dZb, M, CB, CB, T_)
+            dD2 = dD2_res.clone()
+            gemm16.gemm16(z16, zrs, M, T_, CB, g16['bank_dgrad'][0], dD2, H, col_scale=g16['bank_dgrad'][1], ragged=True,
+                          accumulate=True)
+            del z16, zrs
+        else:
+            for k in range(1, K + 1):
+                sub = b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k))
+                Wk = self.w(sub + '/conv1d/kernel')                                      # [k, H, 128]
+                grp.append((self._dgrad_conv_weight(Wk), k * BANK_FILTERS, k, k - 1 - (k - 1) // 2, BANK_FILTERS * (k - 1)))
+        if grp and M >= 128 and BANK_FILTERS % 32 == 0:
             # (M/128 x H/128 tiles alone would leave most of the chip idle: the banks are dealt to S blocks per tile
             # whose partial sums are added to dD2, which starts as the residual path's gradient)
             tiles = ((M + 127) // 128) * ((H + 127) // 128)
@@ -563,7 +621,7 @@ class StageTrainer:
             else:
                 dD2 = torch.empty((M, H), dtype=torch.float32, device=dev)
                 gemm_launch(dZb, M, T_, BANK_FILTERS, CB, H, grp, dD2, H, f32, R=dD2_res, ldr=H, out_f32=True, sum_groups=1)
-        else:                                  # shapes below the convolution kernel's tile: one launch per bank, chained
+        elif grp:                              # shapes below the convolution kernel's tile: one launch per bank, chained
             dD2 = dD2_res.clone()
             for k, (wk, Kk, taps, pad, off) in enumerate(grp, 1):
                 gemm_launch(dZb[:, off:], M, T_, BANK_FILTERS, CB, H, [(wk, Kk, taps, pad, 0)], dD2, H, f32, R=dD2, ldr=H,
