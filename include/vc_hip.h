@@ -375,6 +375,9 @@ typedef struct vc_gemm16_pair {
     const void* d_Bt0;
     const void* d_Bt1;
     int32_t taps0, extra, pad_l, c_off0, c_off1;
+    int32_t row0;               /* first row of X the pair reads; output row r of the pair is X row row0 + r */
+    int32_t nrows0, nrows1;     /* output rows each filter stores (0 = M - row0) */
+    int32_t s_off0, s_off1;     /* atomic_splits only: first entry of d_col_scale of each filter (otherwise c_off0 / c_off1) */
 } vc_gemm16_pair;
 typedef struct vc_gemm16_desc {
     const void* d_X16;          /* [M, ldx >= 2C] float16 from vc_split16 */
@@ -387,10 +390,24 @@ typedef struct vc_gemm16_desc {
     float* d_C;
     int32_t ldc;
     int32_t accumulate;         /* != 0: add to the contents of d_C */
+    int32_t atomic_splits;      /* n >= 1: every (row tile, pair) is computed by n workgroups over n ranges of K that ADD their
+                                 * partial tiles to d_C with float atomics (d_C pre-initialised; summation order not fixed).
+                                 * The weight-gradient form (tf.gradients w.r.t. a conv kernel): rows = (tap, input channel) of
+                                 * shifted, transposed activations from vc_transpose_split16, the contraction runs over the
+                                 * frames, and a pair's c_off0 / c_off1 are ELEMENT offsets of the two filters' [rows, ldc]
+                                 * gradient blocks from d_C (any alignment).  No col_shift, no ragged walk. */
     void* d_workspace;          /* 256-byte aligned, or NULL */
     size_t workspace_bytes;
 } vc_gemm16_desc;
 size_t vc_gemm16_workspace_bytes(int32_t M, int32_t C, int32_t n_pairs);
+/* Operands of the weight-gradient form of vc_gemm16 (contraction over the frames): X [M, C] float32 (+ the prologue
+ * of vc_split16) -> d_out16 rows (si * C + c), si = 0 .. n_shifts-1, each [hi plane (M) | lo plane (M)] float16 of
+ * pro(X)[m + shift0 + si, c] * s_c (0 where that frame leaves its window of T), s_c the power of two that puts channel
+ * c's largest magnitude in [2^14, 2^15); d_row_scale[si * C + c] = 1 / s_c.  d_row_scale holds (n_shifts + 1) * C
+ * floats (the tail is scratch).  M and C: multiples of 64. */
+int vc_transpose_split16(const float* d_X, int32_t M, int32_t C, int32_t ldx, int32_t T, const float* d_scale,
+                         const float* d_shift, int32_t relu, int32_t pool, int32_t shift0, int32_t n_shifts, void* d_out16,
+                         float* d_row_scale, void* stream);
 int vc_gemm16(const vc_gemm16_desc* desc, void* stream);
 
 /* Train-mode FusedBatchNorm bookkeeping (modules.py:77-84, is_training): batch mean / biased

@@ -94,7 +94,8 @@ class W16Item(C.Structure):
 class Gemm16Pair(C.Structure):
     """struct vc_gemm16_pair (include/vc_hip.h)."""
     _fields_ = [('d_Bt0', C.c_void_p), ('d_Bt1', C.c_void_p), ('taps0', C.c_int32), ('extra', C.c_int32),
-                ('pad_l', C.c_int32), ('c_off0', C.c_int32), ('c_off1', C.c_int32)]
+                ('pad_l', C.c_int32), ('c_off0', C.c_int32), ('c_off1', C.c_int32), ('row0', C.c_int32),
+                ('nrows0', C.c_int32), ('nrows1', C.c_int32), ('s_off0', C.c_int32), ('s_off1', C.c_int32)]
 
 
 class Gemm16Desc(C.Structure):
@@ -102,7 +103,8 @@ class Gemm16Desc(C.Structure):
     _fields_ = [('d_X16', C.c_void_p), ('d_row_scale', C.c_void_p), ('M', C.c_int32), ('T', C.c_int32), ('C', C.c_int32),
                 ('ldx', C.c_int32), ('n_pairs', C.c_int32), ('ragged', C.c_int32), ('pairs', Gemm16Pair * 16),
                 ('d_col_scale', C.c_void_p), ('d_col_shift', C.c_void_p), ('d_C', C.c_void_p), ('ldc', C.c_int32),
-                ('accumulate', C.c_int32), ('d_workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+                ('accumulate', C.c_int32), ('atomic_splits', C.c_int32), ('d_workspace', C.c_void_p),
+                ('workspace_bytes', C.c_size_t)]
 
 
 class WgradGroup(C.Structure):
@@ -170,6 +172,8 @@ _SIGS = {
     'vc_weight_layouts': (C.c_int, [_P, C.c_int32, _P]),
     'vc_split16': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, _P, _P, _P]),
     'vc_weights16': (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
+    'vc_transpose_split16': (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int32, _P, _P, _P]),
     'vc_gemm16_workspace_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     'vc_gemm16': (C.c_int, [C.POINTER(Gemm16Desc), _P]),
     'vc_axpby': (C.c_int, [_P, C.c_int32, C.c_float, _P, C.c_int32, C.c_float, _P, C.c_int32, C.c_int32, C.c_int32, _P]),

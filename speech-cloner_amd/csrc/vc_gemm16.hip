@@ -45,6 +45,9 @@ struct G16Pair {
     const void* Bt0;      // [128][K0] float16, K contiguous: per tap [hi plane | lo plane] of the channels
     const void* Bt1;      // [128][K1]
     int32_t taps0, extra, pad_l, c_off0, c_off1, K0, K1;
+    int32_t row0;         // first row of X this pair's row tile 0 reads (0 unless the pairs walk different row ranges)
+    int32_t nrows0, nrows1;   // output rows (counted from row0) each filter stores
+    int32_t s_off0, s_off1;   // first entry of col_scale / col_shift of each filter (= c_off* unless the output is scattered)
 };
 
 struct G16Args {
@@ -55,6 +58,7 @@ struct G16Args {
     const float* col_shift;
     float* Cout;
     int32_t ldc, accumulate, n_pairs, ragged;
+    int32_t zsplit;       // >= 1: blockIdx.z walks its own K range and ADDS its tile to Cout with float atomics (any pair count)
     int32_t xcd_tiles;
     int16_t seg_pair[8][4], seg_first[8][4], seg_count[8][4];
     int32_t ksplit, split_map;           // split_map 1: K range ks on the XCDs == ks (mod ksplit); ksplit divides 8
@@ -95,7 +99,6 @@ gemm16_kernel(G16Args a) {
             rt = blockIdx.x / a.ksplit;
         }
         psel = 0;
-        if (rt * BM >= a.M) return;
     } else if (a.xcd_tiles > 0) {
         const int xcd = blockIdx.x & 7;
         int slot = blockIdx.x >> 3;
@@ -110,9 +113,11 @@ gemm16_kernel(G16Args a) {
     } else {
         psel = a.n_pairs - 1 - (int)blockIdx.y;               // widest pair first
         rt = blockIdx.x;
+        if (a.zsplit >= 1) ks = blockIdx.z;
     }
     const G16Pair pr = a.p[psel];
-    const int m0 = rt * BM;
+    if (rt * BM >= max(pr.nrows0, pr.nrows1)) return;
+    const int m0 = pr.row0 + rt * BM;
     const bool ragged = a.ragged != 0;
     const int ntap_u = pr.taps0 + pr.extra;            // uniform walk: taps of the wider filter
     const int narrow = ragged ? 0x7fffffff : pr.taps0; // taps of the first filter (it has no tap `narrow`)
@@ -253,7 +258,7 @@ gemm16_kernel(G16Args a) {
     // ---------------- prologue
     {
         float* coef = reinterpret_cast<float*>(smem + COEF_OFF);
-        const int ch = tid & 255, oc = (ch < 128 ? pr.c_off0 : pr.c_off1) + (ch & 127);
+        const int ch = tid & 255, oc = (ch < 128 ? pr.s_off0 : pr.s_off1) + (ch & 127);
         const float* src = tid < 256 ? a.col_scale : a.col_shift;
         coef[tid] = src ? src[oc] : (tid < 256 ? 1.0f : 0.0f);
     }
@@ -433,11 +438,15 @@ gemm16_kernel(G16Args a) {
         for (int it = 0; it < 16; ++it) {
             const int h = it * 16 + hr;                    // half-row index: row = h >> 1, half = h & 1
             const int row = h >> 1, half = h & 1;
-            const int gm = m0 + pass * 128 + row;
+            const int lm = rt * BM + pass * 128 + row;     // output row, counted from the pair's row0
             f32x4v vv = *reinterpret_cast<const f32x4v*>(smem + row * EP + half * 512 + l32 * 16);
-            if (gm < a.M) {
-                f32x4v* dst = reinterpret_cast<f32x4v*>(a.Cout + (size_t)gm * a.ldc + (half ? pr.c_off1 : pr.c_off0) + l32 * 4);
-                if (a.accumulate) {
+            if (lm < (half ? pr.nrows1 : pr.nrows0)) {
+                float* dp = a.Cout + (size_t)lm * a.ldc + (half ? pr.c_off1 : pr.c_off0) + l32 * 4;
+                f32x4v* dst = reinterpret_cast<f32x4v*>(dp);
+                if (a.zsplit >= 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dp + e, vv[e]);
+                } else if (a.accumulate) {
                     const f32x4v old = *dst;
                     vv += old;
                     *dst = vv;
@@ -644,6 +653,90 @@ w16_split_kernel(const vc_w16_item* __restrict__ items, const unsigned* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// vc_transpose_split16: the weight-gradient operands.  tf.gradients w.r.t. a conv kernel contracts over the FRAMES:
+// dW[j, c, o] = sum_m X[m + j - pad, c] dY[m, o].  Both operands are therefore laid out frame-contiguous (transposed),
+// the activations once per tap shift s (row (s, c) = channel c read s frames later, zero where that leaves the window),
+// each row split into [hi | lo] float16 planes under ONE power-of-two scale per channel.
+__global__ void __launch_bounds__(256)
+col_absmax_kernel(const float* __restrict__ X, int M, int C, int ldx, const float* __restrict__ scale,
+                  const float* __restrict__ shift, int relu, unsigned* __restrict__ cmax) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const int rb = (M + gridDim.y - 1) / gridDim.y;
+    const int r0 = blockIdx.y * rb, r1 = min(M, r0 + rb);
+    const float sc = scale ? scale[c] : 1.0f, sh = shift ? shift[c] : 0.0f;
+    const bool pro = scale || shift || relu;
+    float mx = 0.0f;
+    bool bad = false;
+    for (int r = r0; r < r1; ++r) {
+        float x = X[(size_t)r * ldx + c];
+        if (pro) x = pro_val(x, sc, sh, relu);
+        bad = bad || !(x == x);
+        mx = fmaxf(mx, fabsf(x));
+    }
+    if (r1 > r0) atomicMax(cmax + c, bad ? 0x7fc00000u : __float_as_uint(mx));
+}
+
+__global__ void __launch_bounds__(256)
+transpose_split16_kernel(const float* __restrict__ X, int M, int C, int ldx, int T, const float* __restrict__ scale,
+                         const float* __restrict__ shift, int relu, int pool, int shift0, _Float16* __restrict__ out,
+                         float* __restrict__ row_scale, const unsigned* __restrict__ cmax) {
+    __shared__ _Float16 th[64][72], tl[64][72];        // [channel][frame], 144-byte rows
+    const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64, si = blockIdx.z, s = shift0 + si;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;          // 16 x float4 channels, 16 rows x 4
+    const int c = c0 + tx * 4;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) sc = *reinterpret_cast<const float4*>(scale + c);
+    if (shift) sh = *reinterpret_cast<const float4*>(shift + c);
+    const bool pro = scale || shift || relu;
+    float cs[4], rs4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) w16_scale(cmax[c + e], cs[e], rs4[e]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 16 * i, m = m0 + r;
+        const int t = m % T, ts = t + s;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ts >= 0 && ts < T) {
+            x = *reinterpret_cast<const float4*>(X + (size_t)(m + s) * ldx + c);
+            if (pro) {
+                x.x = pro_val(x.x, sc.x, sh.x, relu); x.y = pro_val(x.y, sc.y, sh.y, relu);
+                x.z = pro_val(x.z, sc.z, sh.z, relu); x.w = pro_val(x.w, sc.w, sh.w, relu);
+            }
+            if (pool && ts != T - 1) {
+                float4 y = *reinterpret_cast<const float4*>(X + (size_t)(m + s + 1) * ldx + c);
+                if (pro) {
+                    y.x = pro_val(y.x, sc.x, sh.x, relu); y.y = pro_val(y.y, sc.y, sh.y, relu);
+                    y.z = pro_val(y.z, sc.z, sh.z, relu); y.w = pro_val(y.w, sc.w, sh.w, relu);
+                }
+                x.x = fmaxf(x.x, y.x); x.y = fmaxf(x.y, y.y); x.z = fmaxf(x.z, y.z); x.w = fmaxf(x.w, y.w);
+            }
+        }
+        const float xs[4] = {x.x * cs[0], x.y * cs[1], x.z * cs[2], x.w * cs[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const _Float16 hi = (_Float16)xs[e];
+            th[tx * 4 + e][r] = hi;
+            tl[tx * 4 + e][r] = (_Float16)(xs[e] - (float)hi);
+        }
+    }
+    __syncthreads();
+    const int cc = threadIdx.x >> 2, q = threadIdx.x & 3;            // channel row, 16-frame segment
+    _Float16* o = out + ((size_t)si * C + c0 + cc) * (2 * (size_t)M) + m0 + q * 16;
+    const f16x8* ph = reinterpret_cast<const f16x8*>(&th[cc][q * 16]);
+    const f16x8* pl = reinterpret_cast<const f16x8*>(&tl[cc][q * 16]);
+    reinterpret_cast<f16x8*>(o)[0] = ph[0];
+    reinterpret_cast<f16x8*>(o)[1] = ph[1];
+    reinterpret_cast<f16x8*>(o + M)[0] = pl[0];
+    reinterpret_cast<f16x8*>(o + M)[1] = pl[1];
+    if (blockIdx.x == 0 && threadIdx.x < 64) {
+        float s1, r1;
+        w16_scale(cmax[c0 + threadIdx.x], s1, r1);
+        row_scale[(size_t)si * C + c0 + threadIdx.x] = r1;
+    }
+}
+
 static size_t tick_bytes(int ntm) { return ((size_t)ntm * 4 + 255) & ~(size_t)255; }
 
 // K slabs of one plane product walk; how many ways a single-pair launch splits them
@@ -691,6 +784,27 @@ int vc_split16(const float* d_X, int32_t M, int32_t C, int32_t ldx, int32_t T, c
     return VC_OK;
 }
 
+int vc_transpose_split16(const float* d_X, int32_t M, int32_t C, int32_t ldx, int32_t T, const float* d_scale,
+                         const float* d_shift, int32_t relu, int32_t pool, int32_t shift0, int32_t n_shifts, void* d_out16,
+                         float* d_row_scale, void* stream) {
+    VC_REQUIRE(d_X && d_out16 && d_row_scale, "vc_transpose_split16: NULL argument");
+    VC_REQUIRE(M > 0 && T > 0 && M % T == 0 && (M & 63) == 0 && C >= 64 && (C & 63) == 0 && ldx >= C && (ldx & 3) == 0 &&
+               n_shifts >= 1 && n_shifts <= 64 && shift0 > -T && shift0 + n_shifts - 1 < T,
+               "vc_transpose_split16: bad shape M=%d T=%d C=%d ldx=%d shifts %d+%d (M, C: multiples of 64)", M, T, C, ldx, shift0, n_shifts);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    unsigned* cmax = reinterpret_cast<unsigned*>(d_row_scale + (size_t)n_shifts * C);    // scratch behind the scales
+    VC_HIP_CHECK(hipMemsetAsync(cmax, 0, (size_t)C * 4, st));
+    int yb = 2048 / ((C + 255) / 256);
+    yb = yb < 1 ? 1 : (yb > (M + 63) / 64 ? (M + 63) / 64 : yb);
+    hipLaunchKernelGGL(col_absmax_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)yb), dim3(256), 0, st, d_X, M, C, ldx,
+                       d_scale, d_shift, relu, cmax);
+    hipLaunchKernelGGL(transpose_split16_kernel, dim3((unsigned)(M / 64), (unsigned)(C / 64), (unsigned)n_shifts), dim3(256), 0,
+                       st, d_X, M, C, ldx, T, d_scale, d_shift, relu, pool, shift0, reinterpret_cast<_Float16*>(d_out16),
+                       d_row_scale, cmax);
+    VC_HIP_CHECK(hipGetLastError());
+    return VC_OK;
+}
+
 int vc_weights16(const vc_w16_item* d_items, int32_t n_items, uint32_t* d_gmax, int32_t n_groups, void* stream) {
     VC_REQUIRE(d_items && d_gmax && n_items > 0 && n_items <= 65535 && n_groups > 0, "vc_weights16: bad argument");
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -703,9 +817,12 @@ int vc_weights16(const vc_w16_item* d_items, int32_t n_items, uint32_t* d_gmax, 
 
 int vc_gemm16(const vc_gemm16_desc* d, void* stream) {
     VC_REQUIRE(d && d->d_X16 && d->d_C, "vc_gemm16: NULL argument");
-    VC_REQUIRE(d->M > 0 && d->T > 0 && d->M % d->T == 0 && d->C >= 64 && (d->C & 63) == 0 && d->C <= 4096 && d->ldx >= 2 * d->C &&
+    VC_REQUIRE(d->M > 0 && d->T > 0 && d->M % d->T == 0 && d->C >= 64 && (d->C & 63) == 0 && d->C <= 16384 && d->ldx >= 2 * d->C &&
                (d->ldx & 7) == 0, "vc_gemm16: bad shape M=%d T=%d C=%d ldx=%d", d->M, d->T, d->C, d->ldx);
     VC_REQUIRE(d->n_pairs >= 1 && d->n_pairs <= 16 && (d->ldc & 3) == 0, "vc_gemm16: bad pair count / ldc");
+    const bool atomic = d->atomic_splits >= 1;
+    VC_REQUIRE(d->atomic_splits >= 0 && d->atomic_splits <= MAX_SPLIT && !(atomic && (d->d_col_shift || d->ragged)),
+               "vc_gemm16: atomic_splits 0..8, without col_shift / ragged");
     VC_REQUIRE((reinterpret_cast<uintptr_t>(d->d_X16) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->d_C) & 15) == 0, "vc_gemm16: unaligned");
     static bool attr_done = false;
     if (!attr_done) {
@@ -728,9 +845,17 @@ int vc_gemm16(const vc_gemm16_desc* d, void* stream) {
         G16Pair& p = a.p[i];
         VC_REQUIRE(s.d_Bt0 && s.d_Bt1 && (reinterpret_cast<uintptr_t>(s.d_Bt0) & 15) == 0 && (reinterpret_cast<uintptr_t>(s.d_Bt1) & 15) == 0,
                    "vc_gemm16: pair %d: NULL / unaligned weights", i);
-        VC_REQUIRE((s.c_off0 & 3) == 0 && (s.c_off1 & 3) == 0 && s.c_off0 >= 0 && s.c_off1 >= 0 && s.c_off0 + 128 <= d->ldc &&
-                   s.c_off1 + 128 <= d->ldc, "vc_gemm16: pair %d: bad output columns", i);
+        // (atomic accumulation: c_off* are element offsets of each filter's [rows, ldc] block from d_C, any alignment)
+        VC_REQUIRE(s.c_off0 >= 0 && s.c_off1 >= 0 && (atomic || ((s.c_off0 & 3) == 0 && (s.c_off1 & 3) == 0 && s.c_off0 + 128 <= d->ldc &&
+                   s.c_off1 + 128 <= d->ldc)), "vc_gemm16: pair %d: bad output columns", i);
+        VC_REQUIRE(s.row0 >= 0 && s.nrows0 >= 0 && s.nrows1 >= 0 && s.row0 + (s.nrows0 > s.nrows1 ? s.nrows0 : s.nrows1) <= d->M,
+                   "vc_gemm16: pair %d: bad row range", i);
         p.Bt0 = s.d_Bt0; p.Bt1 = s.d_Bt1; p.c_off0 = s.c_off0; p.c_off1 = s.c_off1;
+        p.row0 = s.row0;
+        p.s_off0 = atomic ? s.s_off0 : s.c_off0;
+        p.s_off1 = atomic ? s.s_off1 : s.c_off1;
+        p.nrows0 = s.nrows0 ? s.nrows0 : d->M - s.row0;
+        p.nrows1 = s.nrows1 ? s.nrows1 : d->M - s.row0;
         if (d->ragged) {
             p.taps0 = 0; p.extra = 0; p.pad_l = 0;
             p.K0 = p.K1 = 2 * ((nsl >> 1) * ((nsl >> 1) + 1) / 2) * 128;
@@ -742,9 +867,25 @@ int vc_gemm16(const vc_gemm16_desc* d, void* stream) {
             p.K1 = (s.taps0 + s.extra) * 2 * d->C;
         }
     }
-    const int ntm = (d->M + BM - 1) / BM;
+    int max_rows = 0;
+    for (int i = 0; i < d->n_pairs; ++i) {
+        const int r = a.p[i].nrows0 > a.p[i].nrows1 ? a.p[i].nrows0 : a.p[i].nrows1;
+        max_rows = r > max_rows ? r : max_rows;
+    }
+    const int ntm = (max_rows + BM - 1) / BM;
     const int kslabs = 3 * nsl;
-    int ks = choose_ksplit(d->M, d->n_pairs, kslabs);
+    if (atomic) {
+        // every (row tile, pair, K range) its own workgroup, partial tiles added with float atomics to a pre-initialised C
+        const int zs = d->atomic_splits;
+        VC_REQUIRE(zs <= kslabs, "vc_gemm16: more K ranges than K slabs");
+        a.zsplit = zs;
+        a.ksplit = 1;
+        for (int i = 0; i <= zs; ++i) a.split_cs[i] = (int16_t)((long)kslabs * i / zs);
+        hipLaunchKernelGGL(gemm16_kernel, dim3(ntm, d->n_pairs, zs), dim3(NT), LDS_BYTES, st, a);
+        VC_HIP_CHECK(hipGetLastError());
+        return VC_OK;
+    }
+    int ks = choose_ksplit(max_rows, d->n_pairs, kslabs);
     int split_map = 0;
     const int forced = vc::opt(vc::OPT_GEMM16_SPLIT);
     if (forced >= 1 && d->n_pairs == 1) {

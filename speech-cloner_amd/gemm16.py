@@ -31,24 +31,41 @@ def split16(X, M, Cn, ldx, T, scale=None, shift=None, relu=0, pool=0):
     return out, rs
 
 
+def transpose_split16(X, M, Cn, ldx, T, shift0=0, n_shifts=1, scale=None, shift=None, relu=0, pool=0):
+    """Weight-gradient operand: -> (rows (si * Cn + c) of [hi (M) | lo (M)] float16 = channel c of pro(X) read
+    shift0 + si frames later (0 outside the window), row_scale [n_shifts * Cn] = 1 / the channel's scale (+ scratch))."""
+    torch = _torch()
+    out = torch.empty((n_shifts * Cn, 2 * M), dtype=torch.float16, device=X.device)
+    rs = torch.empty((n_shifts + 1) * Cn, dtype=torch.float32, device=X.device)
+    _vc.check(_vc.lib().vc_transpose_split16(_p(X), M, Cn, ldx, T, _p(scale), _p(shift), int(relu), int(pool), shift0,
+                                             n_shifts, _p(out), _p(rs), _vc.current_stream()))
+    return out, rs
+
+
 def gemm16(X16, rs, M, T, Cn, pairs, out, ldc, col_scale=None, col_shift=None, ragged=False, accumulate=False,
-           workspace=True):
-    """pairs: list of (Bt0, Bt1, taps0, extra, pad_l, c_off0, c_off1) (ragged: taps / pad ignored).  ``workspace``:
-    True = allocate what a split-K launch wants, False = none (one workgroup per row tile), or a uint8 tensor."""
+           workspace=True, atomic_splits=0):
+    """pairs: list of (Bt0, Bt1, taps0, extra, pad_l, c_off0, c_off1[, row0, nrows0, nrows1, s_off0, s_off1]) (ragged:
+    taps / pad ignored).  ``workspace``: True = allocate what a split-K launch wants, False = none (one workgroup per
+    row tile), or a uint8 tensor.  ``atomic_splits`` n >= 1: the weight-gradient form (include/vc_hip.h)."""
     torch = _torch()
     lib = _vc.lib()
     d = _vc.Gemm16Desc()
     d.d_X16, d.d_row_scale = X16.data_ptr(), (rs.data_ptr() if rs is not None else None)
     d.M, d.T, d.C, d.ldx = M, T, Cn, X16.shape[1]
     d.n_pairs, d.ragged = len(pairs), int(bool(ragged))
-    for i, (b0, b1, taps0, extra, pad_l, c0, c1) in enumerate(pairs):
+    for i, pr in enumerate(pairs):
+        b0, b1, taps0, extra, pad_l, c0, c1 = pr[:7]
         p = d.pairs[i]
         p.d_Bt0, p.d_Bt1, p.taps0, p.extra, p.pad_l, p.c_off0, p.c_off1 = b0.data_ptr(), b1.data_ptr(), taps0, extra, pad_l, c0, c1
+        if len(pr) > 7:
+            p.row0, p.nrows0, p.nrows1, p.s_off0, p.s_off1 = pr[7:12]
     d.d_col_scale = col_scale.data_ptr() if col_scale is not None else None
     d.d_col_shift = col_shift.data_ptr() if col_shift is not None else None
-    d.d_C, d.ldc, d.accumulate = out.data_ptr(), ldc, int(bool(accumulate))
+    d.d_C, d.ldc, d.accumulate, d.atomic_splits = out.data_ptr(), ldc, int(bool(accumulate)), int(atomic_splits)
     ws = None
-    if workspace is True:
+    if atomic_splits:
+        pass
+    elif workspace is True:
         nbytes = lib.vc_gemm16_workspace_bytes(M, Cn, len(pairs))
         if nbytes:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=out.device)
@@ -161,3 +178,36 @@ def bank_dgrad_operands(w16, kernels, H):
         w16.add(W, 1, bt, 2 * PL, BANK_FILTERS, PL, BANK_FILTERS * k * (k - 1) // 2, g, col_scale if k == 1 else None,
                 H if k == 1 else 0)
     return [(bt[:128], bt[128:], 0, 0, 0, 0, 128)], col_scale
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# weight gradients (contraction over the frames; include/vc_hip.h vc_gemm16_desc.atomic_splits)
+
+def bank_wgrad(XT16, rsX, dZT16, rsZ, H, K, M, grads, grad_base, splits=6):
+    """Filter gradients of conv1d_banks, ONE launch: dW_k[j, c, o] += sum_m X[m + j - (k-1)//2, c] dZ[m, 128 (k-1) + o].
+    XT16 / rsX: transpose_split16 of the bank input X [M, H] over the K shifts -(K/2 - 1) .. K/2; dZT16 / rsZ: of dZ [M, 128 K]
+    (one shift, 0).  grads[k - 1]: the float32 [k, H, 128] gradient of bank k, a view into ``grad_base`` (pre-zeroed: the
+    K ranges add with float atomics)."""
+    shift0 = -(K // 2 - 1)
+    base = grad_base.data_ptr()
+    pairs = []
+    for p in range(K // 2):
+        k0 = 2 * p + 1
+        o0, o1 = (grads[k0 - 1].data_ptr() - base) // 4, (grads[k0].data_ptr() - base) // 4
+        pairs.append((dZT16[BANK_FILTERS * (k0 - 1):], dZT16[BANK_FILTERS * k0:], 1, 0, 0, o0, o1,
+                      (-p - shift0) * H, k0 * H, (k0 + 1) * H, BANK_FILTERS * (k0 - 1), BANK_FILTERS * k0))
+    rows = K * H
+    gemm16(XT16, rsX, rows, rows, M, pairs, grad_base, BANK_FILTERS, col_scale=rsZ, atomic_splits=splits)
+
+
+def conv3_wgrad(dQT16, rsQ, PT16, rsP, H, CB, M, dW, splits=5):
+    """Filter gradient of the width-3 projection: dW[j, c, o] += sum_m P[m + j - 1, c] dQ[m, o].  dQT16 / rsQ:
+    transpose_split16 of dQ [M, H] over the shifts -1, 0, 1; PT16 / rsP: of the projection's input P [M, CB] (shift 0).
+    The small operand carries the shifts, so the tile comes out as [(shift, o), c] and is transposed into dW [3, CB, H]."""
+    torch = _torch()
+    scratch = torch.zeros((3 * H, CB), dtype=torch.float32, device=dW.device)
+    pairs = [(PT16[256 * i:], PT16[256 * i + 128:], 1, 0, 0, 256 * i, 256 * i + 128, 0, 3 * H, 3 * H, 256 * i, 256 * i + 128)
+             for i in range(CB // 256)]
+    gemm16(dQT16, rsQ, 3 * H, 3 * H, M, pairs, scratch, CB, col_scale=rsP, atomic_splits=splits)
+    # row (si, o): shift s' = si - 1 of dQ <=> tap j = 1 - s' = 2 - si
+    dW.add_(scratch.view(3, H, CB).flip(0).permute(0, 2, 1))

@@ -567,12 +567,21 @@ class StageTrainer:
         # conv1d_1 on pool(relu(bnb(Zb)))
         CB = BANK_FILTERS * K
         W1c = self.w(p1 + '/conv1d/kernel')
-        PT, ldpt = _Ops.transpose(sv['Zb'], M, CB, CB, T_, scale=sv['sb'][0], shift=sv['sb'][1], relu=1, pool=1)
-        dQ1T, ldq1 = _Ops.transpose(dQ1, M, H, H, T_)
-        _Ops.wgrad(PT, ldpt, CB, M, T_, dQ1T, ldq1, [(0, H, 3, -1, self.g(p1 + '/conv1d/kernel'), H)])
-        del PT, dQ1T
-        dP = torch.empty((M, CB), dtype=torch.float32, device=dev)
         g16 = sv.get('g16')
+        wg16 = g16 is not None and M % 64 == 0      # filter gradients on split-float16 operands too (gemm16.py)
+        if wg16:
+            with _Ops.side(sv['Zb'], sv['sb'][0], sv['sb'][1], dQ1):
+                PT, rsP = gemm16.transpose_split16(sv['Zb'], M, CB, CB, T_, scale=sv['sb'][0], shift=sv['sb'][1], relu=1, pool=1)
+                QT, rsQ = gemm16.transpose_split16(dQ1, M, H, H, T_, shift0=-1, n_shifts=3)
+                gemm16.conv3_wgrad(QT, rsQ, PT, rsP, H, CB, M, self.g(p1 + '/conv1d/kernel'),
+                                   splits=max(1, min(8, 256 // (16 * ((3 * H + 255) // 256)))) if _Ops.splits_allowed else 1)
+                del PT, rsP, QT, rsQ
+        else:
+            PT, ldpt = _Ops.transpose(sv['Zb'], M, CB, CB, T_, scale=sv['sb'][0], shift=sv['sb'][1], relu=1, pool=1)
+            dQ1T, ldq1 = _Ops.transpose(dQ1, M, H, H, T_)
+            _Ops.wgrad(PT, ldpt, CB, M, T_, dQ1T, ldq1, [(0, H, 3, -1, self.g(p1 + '/conv1d/kernel'), H)])
+            del PT, dQ1T
+        dP = torch.empty((M, CB), dtype=torch.float32, device=dev)
         if g16 is not None:
             q16, qrs = gemm16.split16(dQ1, M, H, H, T_)
             gemm16.gemm16(q16, qrs, M, T_, H, g16['p1_dgrad'][0], dP, CB, col_scale=g16['p1_dgrad'][1])
@@ -584,14 +593,19 @@ class StageTrainer:
                                self.g(b + '/bn/gamma'), self.g(b + '/bn/beta'))
         del dP
         # banks: filter gradients (one grouped launch) and data gradient accumulated bank by bank
-        D2T, ldd2 = _Ops.transpose(sv['D2'], M, H, H, T_)
-        dZbT, ldzb = _Ops.transpose(dZb, M, CB, CB, T_)
-        grp = []
-        for k in range(1, K + 1):
-            sub = b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k))
-            grp.append((BANK_FILTERS * (k - 1), BANK_FILTERS, k, -((k - 1) // 2), self.g(sub + '/conv1d/kernel'), BANK_FILTERS))
-        _Ops.wgrad(D2T, ldd2, H, M, T_, dZbT, ldzb, grp)
-        del D2T, dZbT
+        kg = [self.g(b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k)) + '/conv1d/kernel') for k in range(1, K + 1)]
+        if wg16:
+            with _Ops.side(sv['D2'], dZb):
+                XT, rsX = gemm16.transpose_split16(sv['D2'], M, H, H, T_, shift0=-(K // 2 - 1), n_shifts=K)
+                ZT, rsZ = gemm16.transpose_split16(dZb, M, CB, CB, T_)
+                gemm16.bank_wgrad(XT, rsX, ZT, rsZ, H, K, M, kg, self.grad, splits=(6 if H >= 256 else 8) if _Ops.splits_allowed else 1)
+                del XT, rsX, ZT, rsZ
+        else:
+            D2T, ldd2 = _Ops.transpose(sv['D2'], M, H, H, T_)
+            dZbT, ldzb = _Ops.transpose(dZb, M, CB, CB, T_)
+            grp = [(BANK_FILTERS * (k - 1), BANK_FILTERS, k, -((k - 1) // 2), kg[k - 1], BANK_FILTERS) for k in range(1, K + 1)]
+            _Ops.wgrad(D2T, ldd2, H, M, T_, dZbT, ldzb, grp)
+            del D2T, dZbT
         # data gradient of the banks: sum over k of conv(dZb[:, bank k], W_k^T flipped) + the residual path -- ONE launch
         # whose groups accumulate in the same tile (vc_gemm_desc.sum_groups), not K short-K launches chained through dD2
         grp = []

@@ -190,6 +190,50 @@ def test_bank_data_gradient_ragged_walk_matches_autograd(K, N):
     _check(outs[2], ref.reshape(M, H), 'bank data gradient K=%d (ragged walk, unsplit)' % K)
 
 
+@pytest.mark.parametrize('H,K', [(128, 8), (256, 32)])
+def test_weight_gradients_match_autograd(H, K):
+    """Filter gradients of the bank and of the width-3 projection (contraction over 1,600 frames in 4 windows) against
+    autograd through the float64 restatement; the K ranges add with float atomics, so two runs agree to rounding only."""
+    import gemm16
+    N, T = 4, 400
+    M, CB = N * T, 128 * K
+    g = torch.Generator().manual_seed(40 + K)
+    x = _rand_acts(N, T, H, 41, heavy=True)
+    dz = _rand_acts(N, T, CB, 42)
+    Ws = [torch.zeros(k, H, 128, dtype=torch.float64, requires_grad=True) for k in range(1, K + 1)]
+    z = torch.cat([_conv_same64(x.double(), W) for W in Ws], dim=2)
+    refs = torch.autograd.grad(z, Ws, dz.double())
+    dev = torch.device('cuda')
+    arena = torch.zeros(sum(W.numel() for W in Ws) + 61, dtype=torch.float32, device=dev)
+    grads, off = [], 61                                   # an odd offset: the atomic form needs no alignment
+    for W in Ws:
+        grads.append(arena[off:off + W.numel()].view(W.shape))
+        off += W.numel()
+    XT, rsX = gemm16.transpose_split16(x.to(dev).view(M, H), M, H, H, T, shift0=-(K // 2 - 1), n_shifts=K)
+    ZT, rsZ = gemm16.transpose_split16(dz.to(dev).view(M, CB), M, CB, CB, T)
+    gemm16.bank_wgrad(XT, rsX, ZT, rsZ, H, K, M, grads, arena)
+    worst = 0.0
+    for k, (gk, rk) in enumerate(zip(grads, refs), 1):
+        l2, mx = _err(gk, rk)
+        worst = max(worst, l2)
+        assert l2 < REL_L2 and mx < REL_MAX, ('bank %d' % k, l2, mx)
+    print('bank filter gradients H=%d K=%d: worst rel L2 %.2e' % (H, K, worst))
+    assert float(arena[:61].abs().max()) == 0.0
+    # projection: P = pool(relu(bn(Zb))) built by the prologue, dQ [M, H]
+    zb = _rand_acts(N, T, CB, 43)
+    sc, sh = torch.rand(CB, generator=g) + 0.5, torch.randn(CB, generator=g)
+    dq = _rand_acts(N, T, H, 44)
+    a = torch.relu(zb.double() * sc.double() + sh.double())
+    P = torch.cat([torch.maximum(a[:, :-1], a[:, 1:]), a[:, -1:]], dim=1)
+    W1 = torch.zeros(3, CB, H, dtype=torch.float64, requires_grad=True)
+    (ref1,) = torch.autograd.grad(_conv_same64(P, W1), W1, dq.double())
+    PT, rsP = gemm16.transpose_split16(zb.to(dev).view(M, CB), M, CB, CB, T, scale=sc.to(dev), shift=sh.to(dev), relu=1, pool=1)
+    QT, rsQ = gemm16.transpose_split16(dq.to(dev).view(M, H), M, H, H, T, shift0=-1, n_shifts=3)
+    dW1 = torch.zeros((3, CB, H), dtype=torch.float32, device=dev)
+    gemm16.conv3_wgrad(QT, rsQ, PT, rsP, H, CB, M, dW1)
+    _check(dW1, ref1, 'projection filter gradient H=%d' % H)
+
+
 def test_bad_arguments_are_refused():
     import gemm16, _vc
     dev = torch.device('cuda')
