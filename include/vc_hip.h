@@ -376,7 +376,8 @@ typedef struct vc_gemm16_pair {
     const void* d_Bt1;
     int32_t taps0, extra, pad_l, c_off0, c_off1;
     int32_t row0;               /* first row of X the pair reads; output row r of the pair is X row row0 + r */
-    int32_t nrows0, nrows1;     /* output rows each filter stores (0 = M - row0) */
+    int32_t nrows0, nrows1;     /* output rows each filter stores (0 = M - row0); nrows1 = -1: the pair is ONE 128-column
+                                 * filter (d_Bt1 is not read, nothing is stored for it) */
     int32_t s_off0, s_off1;     /* atomic_splits only: first entry of d_col_scale of each filter (otherwise c_off0 / c_off1) */
 } vc_gemm16_pair;
 typedef struct vc_gemm16_desc {

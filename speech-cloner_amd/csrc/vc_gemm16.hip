@@ -84,7 +84,6 @@ gemm16_kernel(G16Args a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wid >> 2, wc = wid & 3;             // wave tile: rows wr*128.., cols wc*64.. (wc < 2: the first filter)
     int psel, rt, ks = 0;
     if (a.ksplit > 1) {
         if (a.split_map) {
@@ -117,6 +116,12 @@ gemm16_kernel(G16Args a) {
     }
     const G16Pair pr = a.p[psel];
     if (rt * BM >= max(pr.nrows0, pr.nrows1)) return;
+    // wave tile: rows wr*128.., cols wc*64.. (wc < 2: the first filter).  A pair whose second filter stores nothing is a
+    // single 128-column filter: waves 0-3 (one per SIMD) take its 2 x 2 wave tiles, waves 4-7 only stage operands
+    const bool half_only = pr.nrows1 == 0;
+    const int wr = half_only ? (wid >> 1) & 1 : wid >> 2, wc = half_only ? wid & 1 : wid & 3;
+    const bool dead_wave = half_only && wid >= 4;
+    const int wpass = __builtin_amdgcn_readfirstlane(dead_wave ? 2 : wr);     // epilogue pass this wave writes (2: none)
     const int m0 = pr.row0 + rt * BM;
     const bool ragged = a.ragged != 0;
     const int ntap_u = pr.taps0 + pr.extra;            // uniform walk: taps of the wider filter
@@ -194,7 +199,7 @@ gemm16_kernel(G16Args a) {
         char* dst = Bs + buf * B_BYTES + wid * 1024;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-            if (q >= 2 || w.j < narrow) glds16(b_src[q] + (q < 2 ? koffL : koffR), dst + q * 8192);
+            if (q >= 2 ? !half_only : w.j < narrow) glds16(b_src[q] + (q < 2 ? koffL : koffR), dst + q * 8192);
     };
 
     // ---------------- MFMA roles
@@ -278,7 +283,7 @@ gemm16_kernel(G16Args a) {
     auto tile = [&](int n) {
         const int sh = w0.j - w0.pad;
         const bool need_mask = !(sh >= S_lo && sh < S_hi);
-        const bool active = !(left_wave && w0.j >= narrow);
+        const bool active = !dead_wave && !(left_wave && w0.j >= narrow);
         if (!active) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __syncthreads();
@@ -413,7 +418,7 @@ gemm16_kernel(G16Args a) {
     const int l32 = tid & 31, hr = tid >> 5;               // 32 lanes x 16 B = one 128-channel half row
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
-        if (wr == pass) {
+        if (wpass == pass) {
 #pragma unroll
             for (int c = 0; c < 2; ++c) {
 #pragma unroll
@@ -848,14 +853,14 @@ int vc_gemm16(const vc_gemm16_desc* d, void* stream) {
         // (atomic accumulation: c_off* are element offsets of each filter's [rows, ldc] block from d_C, any alignment)
         VC_REQUIRE(s.c_off0 >= 0 && s.c_off1 >= 0 && (atomic || ((s.c_off0 & 3) == 0 && (s.c_off1 & 3) == 0 && s.c_off0 + 128 <= d->ldc &&
                    s.c_off1 + 128 <= d->ldc)), "vc_gemm16: pair %d: bad output columns", i);
-        VC_REQUIRE(s.row0 >= 0 && s.nrows0 >= 0 && s.nrows1 >= 0 && s.row0 + (s.nrows0 > s.nrows1 ? s.nrows0 : s.nrows1) <= d->M,
+        VC_REQUIRE(s.row0 >= 0 && s.nrows0 >= 0 && s.nrows1 >= -1 && s.row0 + (s.nrows0 > s.nrows1 ? s.nrows0 : s.nrows1) <= d->M,
                    "vc_gemm16: pair %d: bad row range", i);
         p.Bt0 = s.d_Bt0; p.Bt1 = s.d_Bt1; p.c_off0 = s.c_off0; p.c_off1 = s.c_off1;
         p.row0 = s.row0;
         p.s_off0 = atomic ? s.s_off0 : s.c_off0;
         p.s_off1 = atomic ? s.s_off1 : s.c_off1;
         p.nrows0 = s.nrows0 ? s.nrows0 : d->M - s.row0;
-        p.nrows1 = s.nrows1 ? s.nrows1 : d->M - s.row0;
+        p.nrows1 = s.nrows1 < 0 ? 0 : (s.nrows1 ? s.nrows1 : d->M - s.row0);      // -1: a single 128-column filter
         if (d->ragged) {
             p.taps0 = 0; p.extra = 0; p.pad_l = 0;
             p.K0 = p.K1 = 2 * ((nsl >> 1) * ((nsl >> 1) + 1) / 2) * 128;

@@ -136,14 +136,17 @@ def bank_forward_operands(w16, kernels, H):
 
 
 def conv_forward_operands(w16, W):
-    """One float32 [k, cin, 256] kernel as the two 128-column halves of a pair.  -> (pairs, col_scale [256])."""
+    """One float32 [k, cin, cout] kernel, cout = 256 (the two 128-column halves of a pair) or 128 (a single-filter
+    pair).  -> (pairs, col_scale [cout])."""
     torch = _torch()
     k, cin, cout = W.shape
-    assert cout == 256
+    assert cout in (128, 256)
     dev = w16.device
     col_scale = torch.empty(cout, dtype=torch.float32, device=dev)
     bt = torch.empty((cout, k * 2 * cin), dtype=torch.float16, device=dev)
     w16.add(W, 0, bt, k * 2 * cin, 2 * cin, cin, 0, w16.new_group(), col_scale, cout)
+    if cout == 128:
+        return [(bt, bt, k, 0, (k - 1) // 2, 0, 0, 0, 0, -1, 0, 0)], col_scale
     return [(bt[:128], bt[128:], k, 0, (k - 1) // 2, 0, 128)], col_scale
 
 
@@ -164,11 +167,11 @@ def conv_dgrad_operands(w16, W):
 
 
 def bank_dgrad_operands(w16, kernels, H):
-    """Data gradient of conv1d_banks w.r.t. its input (H = 256 channels): ONE ragged launch over dZ [M, 128 K].
-    -> (pairs, col_scale [H])."""
+    """Data gradient of conv1d_banks w.r.t. its input (H = 256 channels: one pair; 128: a single-filter pair): ONE
+    ragged launch over dZ [M, 128 K].  -> (pairs, col_scale [H])."""
     torch = _torch()
     K = len(kernels)
-    assert H == 256 and K <= 32
+    assert H in (128, 256) and K <= 32
     dev = w16.device
     PL = BANK_FILTERS * K * (K + 1) // 2
     col_scale = torch.empty(H, dtype=torch.float32, device=dev)
@@ -177,6 +180,8 @@ def bank_dgrad_operands(w16, kernels, H):
     for k, W in enumerate(kernels, 1):
         w16.add(W, 1, bt, 2 * PL, BANK_FILTERS, PL, BANK_FILTERS * k * (k - 1) // 2, g, col_scale if k == 1 else None,
                 H if k == 1 else 0)
+    if H == 128:
+        return [(bt, bt, 0, 0, 0, 0, 0, 0, 0, -1, 0, 0)], col_scale
     return [(bt[:128], bt[128:], 0, 0, 0, 0, 128)], col_scale
 
 

@@ -184,6 +184,8 @@ class StageTrainer:
         # in the configuration keeps every GEMM on the f32-input MFMA kernels.
         self.f16x3 = bool(c.get('train_f16x3', True))
         self._g16 = {}
+        self._w16_stream = torch.cuda.Stream(device=dev) if torch.cuda.is_available() else None    # float16 weight copies after Adam
+        self._prep_wgrad = False                     # forward pass: build the filter-gradient operands of its activations early
         self.routing = {}
 
     def load_slots(self, ckpt):
@@ -244,14 +246,36 @@ class StageTrainer:
             pl = {'w16': w16, 'version': None}
             pl['bank_fwd'] = gemm16.bank_forward_operands(w16, kern, H)
             pl['p1_dgrad'] = gemm16.conv_dgrad_operands(w16, W1)
-            if H == 256:                                                        # 256 output columns = one pair
+            if H in (128, 256):                                                 # one pair, or a single-filter pair
                 pl['p1_fwd'] = gemm16.conv_forward_operands(w16, W1)
                 pl['bank_dgrad'] = gemm16.bank_dgrad_operands(w16, kern, H)
             self._g16[s] = pl
         if pl['version'] != self.store.version:
             pl['w16'].refresh()
             pl['version'] = self.store.version
+            pl['event'] = None
+        elif pl.get('event') is not None:
+            # rewritten behind the last Adam step on a stream of its own (_refresh_w16_async): first use waits for it
+            _torch().cuda.current_stream().wait_event(pl['event'])
+            pl['event'] = None
         return pl
+
+    def _refresh_w16_async(self):
+        """After Adam: rewrite the float16 operand copies of every stage on their own stream, behind the update and beside
+        whatever the main stream does next (the step's host read-back, the next step's encoder and prenet); the next
+        forward pass waits for the event at its first vc_gemm16 launch of the stage."""
+        torch = _torch()
+        if not self._g16 or self._w16_stream is None:
+            return
+        ws = self._w16_stream
+        ws.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ws):
+            for pl in self._g16.values():
+                pl['w16'].refresh()
+                pl['version'] = self.store.version
+                ev = torch.cuda.Event()
+                ev.record(ws)
+                pl['event'] = ev
 
     # ---------------------------------------------------------------- one stage forward
     def _stage_forward(self, s, X0, cin0, E, K, n_hw, n_out, seed_base):
@@ -305,6 +329,17 @@ class StageTrainer:
             gemm_launch(D2, M, T_, H, H, BANK_FILTERS, groups, Zb, CB, f32, out_f32=True)
         sb = _Ops.bn_stats(Zb, M, CB, self.w(b + '/bn/gamma'), self.w(b + '/bn/beta'),
                            self.w(b + '/bn/moving_mean'), self.w(b + '/bn/moving_variance'))
+        if self._prep_wgrad and g16 is not None and M % 64 == 0 and self._side is not None:
+            # the filter-gradient operands that depend on forward activations only (the bank input over its K tap shifts,
+            # the projection input): built NOW on the side stream, under the rest of the forward pass and the recurrence,
+            # instead of at the tail of the backward pass
+            ws = self._side
+            ws.wait_stream(torch.cuda.current_stream())
+            for t_ in (D2, Zb, sb[0], sb[1]):
+                t_.record_stream(ws)
+            with torch.cuda.stream(ws):
+                sv['XT'] = gemm16.transpose_split16(D2, M, H, H, T_, shift0=-(K // 2 - 1), n_shifts=K)
+                sv['PT'] = gemm16.transpose_split16(Zb, M, CB, CB, T_, scale=sb[0], shift=sb[1], relu=1, pool=1)
         if self.export_routing:
             # parity tests: the relu / pool-winner decisions the backward pass will take on this tensor, for the oracle
             bits = torch.empty((M, CB), dtype=torch.uint8, device=dev)
@@ -571,7 +606,8 @@ class StageTrainer:
         wg16 = g16 is not None and M % 64 == 0      # filter gradients on split-float16 operands too (gemm16.py)
         if wg16:
             with _Ops.side(sv['Zb'], sv['sb'][0], sv['sb'][1], dQ1):
-                PT, rsP = gemm16.transpose_split16(sv['Zb'], M, CB, CB, T_, scale=sv['sb'][0], shift=sv['sb'][1], relu=1, pool=1)
+                PT, rsP = sv.pop('PT') if 'PT' in sv else gemm16.transpose_split16(
+                    sv['Zb'], M, CB, CB, T_, scale=sv['sb'][0], shift=sv['sb'][1], relu=1, pool=1)
                 QT, rsQ = gemm16.transpose_split16(dQ1, M, H, H, T_, shift0=-1, n_shifts=3)
                 gemm16.conv3_wgrad(QT, rsQ, PT, rsP, H, CB, M, self.g(p1 + '/conv1d/kernel'),
                                    splits=max(1, min(8, 256 // (16 * ((3 * H + 255) // 256)))) if _Ops.splits_allowed else 1)
@@ -596,7 +632,8 @@ class StageTrainer:
         kg = [self.g(b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k)) + '/conv1d/kernel') for k in range(1, K + 1)]
         if wg16:
             with _Ops.side(sv['D2'], dZb):
-                XT, rsX = gemm16.transpose_split16(sv['D2'], M, H, H, T_, shift0=-(K // 2 - 1), n_shifts=K)
+                XT, rsX = sv.pop('XT') if 'XT' in sv else gemm16.transpose_split16(
+                    sv['D2'], M, H, H, T_, shift0=-(K // 2 - 1), n_shifts=K)
                 ZT, rsZ = gemm16.transpose_split16(dZb, M, CB, CB, T_)
                 gemm16.bank_wgrad(XT, rsX, ZT, rsZ, H, K, M, kg, self.grad, splits=(6 if H >= 256 else 8) if _Ops.splits_allowed else 1)
                 del XT, rsX, ZT, rsZ
@@ -741,6 +778,7 @@ class StageTrainer:
             self._conv_seen = {k_: v_ for k_, v_ in self.store._cache.items() if isinstance(k_, tuple) and k_[0] == 'conv'}
         self.store.invalidate()                   # kernel-layout copies are stale now ...
         self._refresh_conv_layouts()              # ... except the convolutions', rewritten in place by one launch
+        self._refresh_w16_async()
         self.dec.opt_state[self.opt_scope + '/global_step'] = np.int32(t)
         return t
 
@@ -803,6 +841,7 @@ class DecoderTrainer(StageTrainer):
             _vc.check(_lib().vc_fill(_p(self.grad), 0.0, self.total, _st()))     # wgrad accumulates with atomics
         sd1, sd2 = c['steps_v'][0], c['steps_v'][1]
         seed = self.seed + 1000 * self.step_count
+        self._prep_wgrad = bool(backward)
         with modules.variable_store(self.store):
             s1, s2 = dec._scope + '/step1', dec._scope + '/step2'
             y1, sv1 = self._stage_forward(s1, ppg, n_in, dec._E[0], sd1['num_conv_banks'], sd1['num_highwaynet_blocks'],

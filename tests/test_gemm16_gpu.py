@@ -38,10 +38,10 @@ def _err(got, ref):
     return float(d.norm() / ref.norm()), float(d.abs().max() / ref.abs().max())
 
 
-def _check(got, ref, what, f32_err=None):
+def _check(got, ref, what, f32_err=None, loose=1.0):
     l2, mx = _err(got, ref)
     print('%s: rel L2 %.2e, max %.2e%s' % (what, l2, mx, '' if f32_err is None else '   (float32 MFMA kernel: %.2e / %.2e)' % f32_err))
-    assert l2 < REL_L2 and mx < REL_MAX, (what, l2, mx)
+    assert l2 < REL_L2 * loose and mx < REL_MAX * loose, (what, l2, mx)
     if f32_err is not None:
         assert l2 < 3 * f32_err[0] + 1e-7, (what, l2, f32_err)
 
@@ -111,9 +111,10 @@ def test_bank_forward_pairs_match_float64(H, K, N, heavy):
     _check(out, ref, 'bank forward H=%d K=%d%s' % (H, K, ' heavy-tailed' if heavy else ''), _err(o32, ref))
 
 
-def test_projection_split_k_is_deterministic_and_matches_float64():
+@pytest.mark.parametrize('H', [256, 128])
+def test_projection_split_k_is_deterministic_and_matches_float64(H):
     import gemm16, modules, _vc
-    N, T, CB, H = 3, 400, 1024, 256
+    N, T, CB = 3, 400, 1024
     M = N * T
     x = _rand_acts(N, T, CB, 5)
     g = torch.Generator().manual_seed(6)
@@ -138,8 +139,8 @@ def test_projection_split_k_is_deterministic_and_matches_float64():
     modules.gemm_launch(xd, M, T, CB, CB, H, [(Wd.permute(2, 0, 1).reshape(H, -1).contiguous(), 3 * CB, 3, 1, 0)], o32, H,
                         _vc.VC_F32, epi_shift=bias.to(dev), out_f32=True)
     e32 = _err(o32, ref)
-    _check(outs[0], ref, 'projection, K split over 8', e32)
-    _check(outs[2], ref, 'projection, one workgroup per row tile', e32)
+    _check(outs[0], ref, 'projection H=%d, K split over 8' % H, e32)
+    _check(outs[2], ref, 'projection H=%d, one workgroup per row tile' % H, e32)
 
 
 def test_projection_data_gradient_matches_autograd():
@@ -162,10 +163,10 @@ def test_projection_data_gradient_matches_autograd():
     _check(out, ref.reshape(M, CB), 'projection data gradient (16 pairs)')
 
 
-@pytest.mark.parametrize('K,N', [(8, 3), (32, 2)])
-def test_bank_data_gradient_ragged_walk_matches_autograd(K, N):
+@pytest.mark.parametrize('K,N,H', [(8, 3, 256), (32, 2, 256), (32, 2, 128)])
+def test_bank_data_gradient_ragged_walk_matches_autograd(K, N, H):
     import gemm16
-    T, H = 400, 256
+    T = 400
     M = N * T
     g = torch.Generator().manual_seed(20 + K)
     Ws = [(torch.randn(k, H, 128, generator=g) * (0.3 / (k * H) ** 0.5)).float() for k in range(1, K + 1)]
@@ -186,8 +187,9 @@ def test_bank_data_gradient_ragged_walk_matches_autograd(K, N):
         gemm16.gemm16(d16, rs, M, T, 128 * K, pairs, out, H, col_scale=cs, ragged=True, accumulate=True, workspace=ws)
         outs.append(out)
     assert torch.equal(outs[0], outs[1])
-    _check(outs[0], ref.reshape(M, H), 'bank data gradient K=%d (ragged walk, K split)' % K)
-    _check(outs[2], ref.reshape(M, H), 'bank data gradient K=%d (ragged walk, unsplit)' % K)
+    _check(outs[0], ref.reshape(M, H), 'bank data gradient K=%d H=%d (ragged walk, K split)' % (K, H))
+    _check(outs[2], ref.reshape(M, H), 'bank data gradient K=%d H=%d (ragged walk, unsplit)' % (K, H),
+           loose=2.0)         # ONE float32 accumulation chain over up to 203,000 products: the chain's own rounding
 
 
 @pytest.mark.parametrize('H,K', [(128, 8), (256, 32)])
