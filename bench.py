@@ -488,19 +488,37 @@ def train_measure(rank, world, steps, warmup):
               'allreduce_buckets': buckets}
     roof = None
     if rank == 0:
+        import gemm16
         import modules
-        # dominant kernel of the step: conv_kernel<float> on the step-2 filter bank (forward; the data- and
-        # weight-gradient launches of the same layer do the same FLOPs), HIP events over 20 launches
+        # dominant kernel of the step: gemm16_kernel on the step-2 filter bank (forward; the data- and filter-gradient
+        # launches of the same layer do the same FLOPs), HIP events over 20 launches.  `achieved` is the ALGORITHMIC
+        # rate -- the float32 convolution's 2 * MACs -- against the f32-input MFMA peak, the hardware's own float32
+        # matrix rate; the kernel EXECUTES three float16 products per algorithmic one (`executed`).
+        H, K, M = 256, 32, B * T
+        pre = torch.randn(M, H, device='cuda')
+        kern = [tr.w('decoder/step2/CBHG/conv1d_banks' + ('/conv1d' if k == 1 else '/num_%d/conv1d' % k) + '/conv1d/kernel')
+                for k in range(1, K + 1)]
+        w16 = gemm16.Weights16(pre.device)
+        pairs, cs = gemm16.bank_forward_operands(w16, kern, H)
+        w16.refresh()
+        x16, rs = gemm16.split16(pre, M, H, H, T)
+        zb = torch.empty((M, 128 * K), device='cuda')
+        ms_bank = time_events(lambda: gemm16.gemm16(x16, rs, M, T, H, pairs, zb, 128 * K, col_scale=cs), 20)
+        ms_split = time_events(lambda: gemm16.split16(pre, M, H, H, T), 20)
         with modules.variable_store(dec.store), modules.variable_scope('decoder'), modules.variable_scope('step2'), \
                 modules.variable_scope('CBHG'):
-            pre = torch.randn(B, T, 256, device='cuda')
-            ms_bank = time_events(lambda: modules.conv1d_banks(pre, K=32, is_training=False), 20)
+            ms_f32 = time_events(lambda: modules.conv1d_banks(pre.view(B, T, H), K=32, is_training=False), 20)
         fl_bank = 2.0 * 256 * 128 * 528 * B * T
         ach = fl_bank / (ms_bank * 1e-3) / 1e12
-        roof = {'kernel': 'conv_kernel<float> (decoder step2 conv1d_banks forward, exact-f32 MFMA)', 'bound': 'mfma',
+        roof = {'kernel': 'gemm16_kernel (decoder step2 conv1d_banks forward: float32 convolution as 3 float16 MFMA products '
+                          'of exactly split operands)', 'bound': 'mfma',
                 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
                 'frac': round(ach / MFMA_F32_PEAK_TF, 4), 'traffic': None,
                 'algorithmic_flop_per_launch': fl_bank, 'avg_kernel_ms': round(ms_bank, 4),
+                'executed': {'TFLOP/s': round(3 * ach, 1), 'peak': MFMA_BF16_PEAK_TF, 'frac': round(3 * ach / MFMA_BF16_PEAK_TF, 4),
+                             'products_per_algorithmic_flop': 3},
+                'operand_split_ms': round(ms_split, 4),
+                'f32_mfma_kernel_ms': round(ms_f32, 4),
                 'timing': 'HIP events on the launch stream, average of 20 back-to-back launches'}
         stages['step_TFLOPs_at_3x_forward'] = round(3 * DEC_FLOP_PER_FRAME * B * T / (dt / steps) / 1e12, 1)
         stages['step_frac_of_f32_mfma_peak'] = round(stages['step_TFLOPs_at_3x_forward'] / MFMA_F32_PEAK_TF, 4)
@@ -533,7 +551,8 @@ def train_side_measurement(rank, world, reduce_device='cuda'):
             'ms_per_step': round(dt / steps * 1e3, 4), 'steps': steps, 'warmup': warmup,
             'frames_per_s': round(frames * world * steps / dt, 1), 'step_TFLOPs': stages.get('step_TFLOPs_at_3x_forward'),
             'step_frac_of_f32_mfma_peak': stages.get('step_frac_of_f32_mfma_peak'),
-            'roofline': None if roof is None else {k: roof[k] for k in ('kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_kernel_ms')},
+            'roofline': None if roof is None else {k: roof[k] for k in ('kernel', 'achieved', 'peak', 'unit', 'frac', 'avg_kernel_ms',
+                                                                         'executed', 'f32_mfma_kernel_ms')},
             'allreduce_ms': stages['allreduce_ms'], 'allreduce_busbw_GBps': stages['allreduce_busbw_GBps'],
             'allreduce_buckets': stages['allreduce_buckets'], 'last_loss': stages['last_loss']}
 

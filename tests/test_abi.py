@@ -94,7 +94,8 @@ def test_every_struct_field_sits_where_the_header_puts_it(tmp_path):
     from conftest import ROOT
     pairs = [('vc_frontend_cfg', _vc.FrontendCfg), ('vc_gemm_group', _vc.GemmGroup), ('vc_gemm_desc', _vc.GemmDesc),
              ('vc_wgrad_group', _vc.WgradGroup), ('vc_wgrad_desc', _vc.WgradDesc), ('vc_layout_item', _vc.LayoutItem),
-             ('vc_cbhg_front_desc', _vc.CbhgFrontDesc)]
+             ('vc_cbhg_front_desc', _vc.CbhgFrontDesc), ('vc_w16_item', _vc.W16Item), ('vc_gemm16_pair', _vc.Gemm16Pair),
+             ('vc_gemm16_desc', _vc.Gemm16Desc)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "vc_hip.h"', 'int main(void) {']
     for cname, cls in pairs:
         lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
@@ -218,3 +219,40 @@ def test_workspace_queries_are_host_only():
     with _vc.throughput_mode():
         assert _vc.get_option('fe_fused') == 0 and _vc.get_option('proj256_split') == 0
     assert _vc.get_option('fe_fused') == -1
+
+
+def test_split_float16_entry_points_validate_on_the_host():
+    """vc_gemm16 / vc_split16 / vc_transpose_split16 refuse bad shapes before anything is launched (no GPU needed), and the
+    workspace query is pure host arithmetic."""
+    import _vc
+    h = _vc.lib()
+    assert h.vc_gemm16_workspace_bytes(12800, 4096, 1) == 256 + 50 * 8 * 262144     # 50 row tiles, up to 8 K ranges each
+    assert h.vc_gemm16_workspace_bytes(12800, 256, 16) == 0                          # many pairs: never split
+    assert h.vc_gemm16_workspace_bytes(12800, 100, 1) == 0                           # not a multiple of 64
+    assert h.vc_split16(None, 400, 128, 128, 400, None, None, 0, 0, None, None, None) == 1      # VC_ERR_INVALID
+    d = _vc.Gemm16Desc()
+    assert h.vc_gemm16(ctypes.byref(d), None) == 1      # VC_ERR_INVALID
+    assert b'vc_gemm16' in h.vc_last_error()
+
+
+def test_the_tile_kernels_keep_their_accumulators_in_registers():
+    """bank256_kernel and gemm16_kernel hold 128 accumulator registers per lane at 2 waves per SIMD: a source change that
+    tips the allocation over 256 registers turns into scratch spills and a several-fold slowdown with correct results
+    (it happened once: a per-wave epilogue predicate).  The compiler's own resource report must say 0 spills."""
+    import os
+    import re
+    import subprocess
+    from conftest import ROOT
+    csrc = os.path.join(ROOT, 'speech-cloner_amd', 'csrc')
+    for src, kern in (('vc_gemm16.hip', 'gemm16_kernel'), ('vc_bank256.hip', 'bank256_kernel')):
+        out = subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-fno-slp-vectorize', '-std=c++17', '--offload-arch=gfx950',
+                              '--cuda-device-only', '-I', os.path.join(ROOT, 'include'), '-I', csrc, '-c', os.path.join(csrc, src),
+                              '-o', os.devnull, '-Rpass-analysis=kernel-resource-usage'], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-2000:]
+        blocks = out.stderr.split('Function Name:')
+        mine = [b for b in blocks if kern in b.splitlines()[0]]
+        assert mine, 'no resource report for %s' % kern
+        spill = re.search(r'VGPRs Spill: (\d+)', mine[0])
+        scratch = re.search(r'ScratchSize \[bytes/lane\]: (\d+)', mine[0])
+        assert spill and int(spill.group(1)) == 0, (kern, mine[0])
+        assert scratch and int(scratch.group(1)) == 0, (kern, mine[0])
