@@ -506,31 +506,38 @@ class StageTrainer:
         whT_fw, whT_bw = wh_fw.t().contiguous(), wh_bw.t().contiguous()
         _vc.check(_lib().vc_gru_backward(_p(dG), _p(sv['G']), _p(sv['gates']), _p(wh_fw), _p(wh_bw), _p(whT_fw), _p(whT_bw),
                                          N_, T_, H, _p(dpre), _st()))
-        dbx = torch.empty(6 * H, dtype=torch.float32, device=dev)
-        _Ops.col_sum(dpre, M, 6 * H, 6 * H, dbx)
-        dpT, ldp = _Ops.transpose(dpre, M, 6 * H, 6 * H, T_)
+        # input gradient first (the critical path): dYn = dpre @ Btx  (Btx [6H, H] -> transposed operand [H, 6H]) ...
+        dYn = self._dgrad_dense(dpre, 6 * H, 6 * H, sv['btx'].t().contiguous(), M, T_)
+        # ... then the weight gradients, one stretch of the side stream
         Yn = sv['Ys'][-1]
-        YT, ldt = _Ops.transpose(Yn, M, H, H, T_)
-        grp_x = []
-        for d, dn in enumerate(('fw', 'bw')):
-            cell = '{}/bidirectional_rnn/{}/gru_cell'.format(gs, dn)
-            gk, ck = self.g(cell + '/gates/kernel'), self.g(cell + '/candidate/kernel')       # [2H,2H], [2H,H]
-            with _Ops.side(dbx):                                   # (dbx was summed on the side stream)
-                self.g(cell + '/gates/bias').copy_(dbx[d * 3 * H:d * 3 * H + 2 * H])
-                self.g(cell + '/candidate/bias').copy_(dbx[d * 3 * H + 2 * H:(d + 1) * 3 * H])
-            grp_x.append((d * 3 * H, 2 * H, 1, 0, gk[:H], 2 * H))                              # x rows of gates/kernel
-            grp_x.append((d * 3 * H + 2 * H, H, 1, 0, ck[:H], H))                              # x rows of candidate/kernel
-        _Ops.wgrad(YT, ldt, H, M, T_, dpT, ldp, grp_x)
-        for d, dn in enumerate(('fw', 'bw')):
-            cell = '{}/bidirectional_rnn/{}/gru_cell'.format(gs, dn)
-            gk, ck = self.g(cell + '/gates/kernel'), self.g(cell + '/candidate/kernel')
-            Gd = sv['G'][:, d * H:(d + 1) * H]                                                  # view, ld = 2H
-            HpT, ldh = _Ops.transpose(Gd, M, H, 2 * H, T_, row_shift=(-1 if d == 0 else 1))   # h_{prev}
-            _Ops.wgrad(HpT, ldh, H, M, T_, dpT, ldp, [(d * 3 * H, 2 * H, 1, 0, gk[H:], 2 * H)])
-            RT, ldr = _Ops.transpose(sv['rh'][d], M, H, H, T_)
-            _Ops.wgrad(RT, ldr, H, M, T_, dpT, ldp, [(d * 3 * H + 2 * H, H, 1, 0, ck[H:], H)])
-        # input gradient: dYn = dpre @ Btx  (Btx [6H, H] -> transposed operand [H, 6H])
-        return self._dgrad_dense(dpre, 6 * H, 6 * H, sv['btx'].t().contiguous(), M, T_)
+        with _Ops.side(dpre, Yn, sv['G'], sv['rh']):
+            inner, _Ops.side_stream = _Ops.side_stream, None              # already there: the wrappers must not re-enter
+            try:
+                dbx = torch.empty(6 * H, dtype=torch.float32, device=dev)
+                _Ops.col_sum(dpre, M, 6 * H, 6 * H, dbx)
+                dpT, ldp = _Ops.transpose(dpre, M, 6 * H, 6 * H, T_)
+                YT, ldt = _Ops.transpose(Yn, M, H, H, T_)
+                grp_x = []
+                for d, dn in enumerate(('fw', 'bw')):
+                    cell = '{}/bidirectional_rnn/{}/gru_cell'.format(gs, dn)
+                    gk, ck = self.g(cell + '/gates/kernel'), self.g(cell + '/candidate/kernel')       # [2H,2H], [2H,H]
+                    self.g(cell + '/gates/bias').copy_(dbx[d * 3 * H:d * 3 * H + 2 * H])
+                    self.g(cell + '/candidate/bias').copy_(dbx[d * 3 * H + 2 * H:(d + 1) * 3 * H])
+                    grp_x.append((d * 3 * H, 2 * H, 1, 0, gk[:H], 2 * H))                              # x rows of gates/kernel
+                    grp_x.append((d * 3 * H + 2 * H, H, 1, 0, ck[:H], H))                              # x rows of candidate/kernel
+                _Ops.wgrad(YT, ldt, H, M, T_, dpT, ldp, grp_x)
+                for d, dn in enumerate(('fw', 'bw')):
+                    cell = '{}/bidirectional_rnn/{}/gru_cell'.format(gs, dn)
+                    gk, ck = self.g(cell + '/gates/kernel'), self.g(cell + '/candidate/kernel')
+                    Gd = sv['G'][:, d * H:(d + 1) * H]                                                  # view, ld = 2H
+                    HpT, ldh = _Ops.transpose(Gd, M, H, 2 * H, T_, row_shift=(-1 if d == 0 else 1))   # h_{prev}
+                    _Ops.wgrad(HpT, ldh, H, M, T_, dpT, ldp, [(d * 3 * H, 2 * H, 1, 0, gk[H:], 2 * H)])
+                    RT, ldr = _Ops.transpose(sv['rh'][d], M, H, H, T_)
+                    _Ops.wgrad(RT, ldr, H, M, T_, dpT, ldp, [(d * 3 * H + 2 * H, H, 1, 0, ck[H:], H)])
+                del dpT, YT, HpT, RT, dbx
+            finally:
+                _Ops.side_stream = inner
+        return dYn
 
     def _stage_backward_front(self, s, sv, dYc, need_dx):
         """Everything in front of the recurrence: highway blocks, projections, filter bank, prenet."""
@@ -543,6 +550,7 @@ class StageTrainer:
         inv_keep = 1.0 / self.keep if self.keep < 1.0 else 1.0
 
         # ---- highways (reverse)
+        side_jobs = []
         for i in range(n_hw - 1, -1, -1):
             hs = s + '/CBHG/highwaynet_{}'.format(i)
             bt, bias = modules._prep_highway(self.store, hs, H)
@@ -556,32 +564,44 @@ class StageTrainer:
             dp = torch.empty((M, NP), dtype=torch.float32, device=dev)
             dXd = torch.empty((M, H), dtype=torch.float32, device=dev)
             _vc.check(_lib().vc_highway_backward(_p(pre), NP, _p(Xi), _p(dYc), M, H, _p(dp), _p(dXd), _st()))
-            XT, ldx = _Ops.transpose(Xi, M, H, H, T_)
-            dpT, ldp = _Ops.transpose(dp, M, NP, NP, T_)
-            dbp = torch.empty(NP, dtype=torch.float32, device=dev)
-            _Ops.col_sum(dp, M, NP, NP, dbp)
-            g1, g2 = self.g(hs + '/dense1/kernel'), self.g(hs + '/dense2/kernel')
-            b1, b2 = self.g(hs + '/dense1/bias'), self.g(hs + '/dense2/bias')
-            grp = []
-            for q in range((H + 31) // 32):
-                n = min(32, H - 32 * q)
-                grp.append((64 * q, n, 1, 0, g1[:, 32 * q:], H))
-                grp.append((64 * q + 32, n, 1, 0, g2[:, 32 * q:], H))
-            with _Ops.side(dbp):                                   # (dbp was summed on the side stream)
-                if H % 32 == 0:        # paired order [32 x dense1 | 32 x dense2] per 32 units -> the two bias vectors: two strided copies
-                    pr = dbp.view(H // 32, 2, 32)
-                    b1.view(H // 32, 32).copy_(pr[:, 0])
-                    b2.view(H // 32, 32).copy_(pr[:, 1])
-                else:
-                    for q in range((H + 31) // 32):
-                        n = min(32, H - 32 * q)
-                        b1[32 * q:32 * q + n].copy_(dbp[64 * q:64 * q + n])
-                        b2[32 * q:32 * q + n].copy_(dbp[64 * q + 32:64 * q + 32 + n])
-            for j in range(0, len(grp), 32):
-                _Ops.wgrad(XT, ldx, H, M, T_, dpT, ldp, grp[j:j + 32])
-            # dX = dp @ bt (paired) + direct path
+            # dX = dp @ bt (paired) + direct path: the critical path goes on first ...
             dYc = self._dgrad_dense(dp, NP, NP, bt.t().contiguous(), M, T_, R=dXd)
-            del pre, dp, XT, dpT
+            side_jobs.append((hs, Xi, dp, NP))
+            del pre, dp
+        # ... then everything only the optimiser needs, for ALL the blocks as one stretch of the side stream (one
+        # cross-stream dependency for the chain instead of several per block: the main stream ran at most ~3 blocks
+        # ahead of the side stream's backlog otherwise and sat idle for the rest)
+        if side_jobs:
+            with _Ops.side(*[t for job in side_jobs for t in job[1:3]]):
+                inner, _Ops.side_stream = _Ops.side_stream, None          # already there: the wrappers must not re-enter
+                try:
+                    for hs, Xi, dp, NP in side_jobs:
+                        g1, g2 = self.g(hs + '/dense1/kernel'), self.g(hs + '/dense2/kernel')
+                        b1, b2 = self.g(hs + '/dense1/bias'), self.g(hs + '/dense2/bias')
+                        grp = []
+                        for q in range((H + 31) // 32):
+                            n = min(32, H - 32 * q)
+                            grp.append((64 * q, n, 1, 0, g1[:, 32 * q:], H))
+                            grp.append((64 * q + 32, n, 1, 0, g2[:, 32 * q:], H))
+                        XT, ldx = _Ops.transpose(Xi, M, H, H, T_)
+                        dpT, ldp = _Ops.transpose(dp, M, NP, NP, T_)
+                        dbp = torch.empty(NP, dtype=torch.float32, device=dev)
+                        _Ops.col_sum(dp, M, NP, NP, dbp)
+                        if H % 32 == 0:    # paired order [32 x dense1 | 32 x dense2] per 32 units -> the two bias vectors: two strided copies
+                            pr = dbp.view(H // 32, 2, 32)
+                            b1.view(H // 32, 32).copy_(pr[:, 0])
+                            b2.view(H // 32, 32).copy_(pr[:, 1])
+                        else:
+                            for q in range((H + 31) // 32):
+                                n = min(32, H - 32 * q)
+                                b1[32 * q:32 * q + n].copy_(dbp[64 * q:64 * q + n])
+                                b2[32 * q:32 * q + n].copy_(dbp[64 * q + 32:64 * q + 32 + n])
+                        for j in range(0, len(grp), 32):
+                            _Ops.wgrad(XT, ldx, H, M, T_, dpT, ldp, grp[j:j + 32])
+                        del XT, dpT, dbp
+                finally:
+                    _Ops.side_stream = inner
+            del side_jobs
 
         # ---- Y0 = bn2(Q2) + D2
         p2 = s + '/CBHG/conv1d_2'
