@@ -439,24 +439,34 @@ gemm16_kernel(G16Args a) {
             }
         }
         __syncthreads();
+        if (a.zsplit >= 1) {
+            // float atomics, one 256-byte row segment per wave instruction (64 consecutive floats: the full atomic rate;
+            // a lane-strided form of the same adds ran at a quarter of it)
 #pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int h = it * 16 + hr;                    // half-row index: row = h >> 1, half = h & 1
-            const int row = h >> 1, half = h & 1;
-            const int lm = rt * BM + pass * 128 + row;     // output row, counted from the pair's row0
-            f32x4v vv = *reinterpret_cast<const f32x4v*>(smem + row * EP + half * 512 + l32 * 16);
-            if (lm < (half ? pr.nrows1 : pr.nrows0)) {
-                float* dp = a.Cout + (size_t)lm * a.ldc + (half ? pr.c_off1 : pr.c_off0) + l32 * 4;
-                f32x4v* dst = reinterpret_cast<f32x4v*>(dp);
-                if (a.zsplit >= 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dp + e, vv[e]);
-                } else if (a.accumulate) {
-                    const f32x4v old = *dst;
-                    vv += old;
-                    *dst = vv;
-                } else {
-                    __builtin_nontemporal_store(vv, dst);
+            for (int it = 0; it < 64; ++it) {
+                const int flat = it * NT + tid;            // element of the [128][256] half tile
+                const int row = flat >> 8, col = flat & 255, half = col >> 7;
+                const int lm = rt * BM + pass * 128 + row;
+                const float v = *reinterpret_cast<const float*>(smem + row * EP + col * 4);
+                if (lm < (half ? pr.nrows1 : pr.nrows0))
+                    unsafeAtomicAdd(a.Cout + (size_t)lm * a.ldc + (half ? pr.c_off1 : pr.c_off0) + (col & 127), v);
+            }
+        } else {
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int h = it * 16 + hr;                    // half-row index: row = h >> 1, half = h & 1
+                const int row = h >> 1, half = h & 1;
+                const int lm = rt * BM + pass * 128 + row;     // output row, counted from the pair's row0
+                f32x4v vv = *reinterpret_cast<const f32x4v*>(smem + row * EP + half * 512 + l32 * 16);
+                if (lm < (half ? pr.nrows1 : pr.nrows0)) {
+                    f32x4v* dst = reinterpret_cast<f32x4v*>(a.Cout + (size_t)lm * a.ldc + (half ? pr.c_off1 : pr.c_off0) + l32 * 4);
+                    if (a.accumulate) {
+                        const f32x4v old = *dst;
+                        vv += old;
+                        *dst = vv;
+                    } else {
+                        __builtin_nontemporal_store(vv, dst);
+                    }
                 }
             }
         }

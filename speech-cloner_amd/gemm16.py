@@ -188,7 +188,7 @@ def bank_dgrad_operands(w16, kernels, H):
 # ---------------------------------------------------------------------------------------------------------------------
 # weight gradients (contraction over the frames; include/vc_hip.h vc_gemm16_desc.atomic_splits)
 
-def bank_wgrad(XT16, rsX, dZT16, rsZ, H, K, M, grads, grad_base, splits=6):
+def bank_wgrad(XT16, rsX, dZT16, rsZ, H, K, M, grads, grad_base, splits=2):
     """Filter gradients of conv1d_banks, ONE launch: dW_k[j, c, o] += sum_m X[m + j - (k-1)//2, c] dZ[m, 128 (k-1) + o].
     XT16 / rsX: transpose_split16 of the bank input X [M, H] over the K shifts -(K/2 - 1) .. K/2; dZT16 / rsZ: of dZ [M, 128 K]
     (one shift, 0).  grads[k - 1]: the float32 [k, H, 128] gradient of bank k, a view into ``grad_base`` (pre-zeroed: the

@@ -655,7 +655,7 @@ class StageTrainer:
                 XT, rsX = sv.pop('XT') if 'XT' in sv else gemm16.transpose_split16(
                     sv['D2'], M, H, H, T_, shift0=-(K // 2 - 1), n_shifts=K)
                 ZT, rsZ = gemm16.transpose_split16(dZb, M, CB, CB, T_)
-                gemm16.bank_wgrad(XT, rsX, ZT, rsZ, H, K, M, kg, self.grad, splits=(6 if H >= 256 else 8) if _Ops.splits_allowed else 1)
+                gemm16.bank_wgrad(XT, rsX, ZT, rsZ, H, K, M, kg, self.grad, splits=2 if _Ops.splits_allowed else 1)      # (1 .. 8 ranges measure the same: ab_gemm16.log)
                 del XT, rsX, ZT, rsZ
         else:
             D2T, ldd2 = _Ops.transpose(sv['D2'], M, H, H, T_)

@@ -370,7 +370,8 @@ def _compare_gradients(tr, g_dev, grads, tol_max=1e-4, tol_l2=1e-4):
     assert worst_l2[1] < tol_l2, 'worst relative L2 gradient error %s: %.3e' % worst_l2
 
 
-def test_hp_size_train_step_matches_autograd():
+@pytest.mark.parametrize('f16x3', [True, False])
+def test_hp_size_train_step_matches_autograd(f16x3):
     """SURVEY section 8 row a23 at the SHIPPED sizes (hp/decoder_cfg_d.json: E = 256 / 512, K = 32 banks, 4 / 6
     highway layers, T = 400; /root/reference/decoder.py:185-263, 327-345): one decoder step on 2 windows -- both
     losses, every gradient (grouped K = 32 weight-gradient launches, H = 128 / 256 recurrences through time), the
@@ -389,12 +390,20 @@ def test_hp_size_train_step_matches_autograd():
     (stored output > 0, as vc_relu_dropout_backward reads it), every highway block's relu (re-computed pre-activation
     > 0, as vc_highway_backward reads it) -- and the oracle takes them as GIVEN routing (model_oracle.dense /
     conv1d_banks / max_pool_2_same / cbhg): values move by at most the rounding that made the decision arbitrary, the
-    gradients follow one route on both sides, and what is left is float32 summation error."""
+    gradients follow one route on both sides, and what is left is float32 summation error.
+
+    f16x3: the filter bank and the first projection (forward, data gradients) as three float16 MFMA products of exactly
+    split float32 operands (csrc/vc_gemm16.hip; the default) or, 'train_f16x3': False, on the f32-input MFMA kernels --
+    the same bounds for both (measured: worst 4.5e-6 / 5.0e-6 on the split path, 8.0e-6 / 6.1e-6 on the f32-MFMA path)
+    -- the filter gradients of this 800-frame batch stay on wgrad_kernel (frame count not a multiple of 64); the
+    32-window test below runs them on the split path."""
     cfg = _hp_cfg()
+    cfg['train_f16x3'] = f16x3
     assert cfg['steps_v'][0]['num_conv_banks'] == 32 and cfg['steps_v'][1]['embed_size'] == 512
     dec, w, ppg, t_mel, t_stft = _setup(cfg, N=2)
     tr = dec._get_trainer()
     tr.export_routing = True
+    assert tr.f16x3 == f16x3
     assert tr.total == 33186713                                   # SURVEY section 8a row a20: trainable parameters
     x = torch.from_numpy(ppg).cuda()
     losses = tr.forward_backward(x, torch.from_numpy(t_mel).cuda(), torch.from_numpy(t_stft).cuda())

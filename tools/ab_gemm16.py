@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'speech-cloner_amd')):
     sys.path.insert(0, p)
-import torch, gemm16, modules, _vc
+import torch, gemm16, modules, training, _vc
 
 dev = torch.device('cuda')
 N, T = 32, 400
@@ -63,6 +63,32 @@ def main():
         d16, drs = gemm16.split16(dq, M, H, H, T)
         t16 = timed(lambda: gemm16.gemm16(d16, drs, M, T, H, dp, out, CB, col_scale=dcs))
         report('H=%d projection data gradient' % H, flop, t32, t16, ts)
+        # bank filter gradients (12,800-frame contraction): transposes + wgrad_kernel vs transposed splits + gemm16 (atomics)
+        grads = [torch.zeros_like(W) for W in Ws]
+        arena = torch.zeros(sum(W.numel() for W in Ws), device=dev)
+        views, off = [], 0
+        for W in Ws:
+            views.append(arena[off:off + W.numel()].view(W.shape))
+            off += W.numel()
+
+        def f32_wgrad():
+            xt, ldx = training._Ops.transpose(x, M, H, H, T)
+            zt, ldz = training._Ops.transpose(zb, M, CB, CB, T)
+            grp = [(128 * (k - 1), 128, k, -((k - 1) // 2), grads[k - 1], 128) for k in range(1, K + 1)]
+            training._Ops.wgrad(xt, ldx, H, M, T, zt, ldz, grp)
+
+        def f16_prep():
+            return (gemm16.transpose_split16(x, M, H, H, T, shift0=-(K // 2 - 1), n_shifts=K),
+                    gemm16.transpose_split16(zb, M, CB, CB, T))
+        (XT, rsX), (ZT, rsZ) = f16_prep()
+        flop = 2.0 * M * 528 * H * 128
+        t32 = timed(f32_wgrad)
+        ts = timed(f16_prep)
+        t16 = timed(lambda: gemm16.bank_wgrad(XT, rsX, ZT, rsZ, H, K, M, views, arena, splits=6 if H >= 256 else 8))
+        report('H=%d bank filter gradients (incl. operand transposes)' % H, flop, t32, t16, ts)
+        print('      K ranges per tile (float atomics): ' + '   '.join('%d: %.3f ms' % (sp, timed(lambda: gemm16.bank_wgrad(
+            XT, rsX, ZT, rsZ, H, K, M, views, arena, splits=sp))) for sp in (1, 2, 3, 4, 6, 8)))
+        del XT, ZT
         if H != 256:
             continue
         # projection forward on pool(relu(bn(Zb)))
