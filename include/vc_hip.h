@@ -71,6 +71,8 @@ const char* vc_target_arch(void);
  *   "gru_train_resident" 0 = the float32 training recurrences stream all their weights from L2 every step (default:
  *                    128 units: all of them in registers, forward and backward; 256 units: half, forward)
  *   "cbhg_front_mi"  4 = 128-row blocks in the fused encoder front
+ *   "f32_f16x3"      0 = float32 INFERENCE keeps its filter banks / post-bank projections on the f32-input MFMA kernels
+ *                    (default: three float16 products of exactly split operands, vc_gemm16: float32-accurate)
  *   "gemm16_split"   vc_gemm16, single-pair launches: ways K is split over workgroups (1..8) + 16 * block map (0 = the splits
  *                    of a row tile on one XCD, 1 = one K range per XCD: ways must divide 8); default: chosen from the shape
  * All alternatives compute the same function (tests compare them).  Three more names, "ablate_bank256",
@@ -390,7 +392,8 @@ typedef struct vc_gemm16_desc {
     const float* d_col_shift;
     float* d_C;
     int32_t ldc;
-    int32_t accumulate;         /* != 0: add to the contents of d_C */
+    int32_t accumulate;         /* != 0: add to the contents of d_C (after the activation: a residual) */
+    int32_t act;                /* VC_ACT_NONE | VC_ACT_RELU, applied to acc * scales + shift */
     int32_t atomic_splits;      /* n >= 1: every (row tile, pair) is computed by n workgroups over n ranges of K that ADD their
                                  * partial tiles to d_C with float atomics (d_C pre-initialised; summation order not fixed).
                                  * The weight-gradient form (tf.gradients w.r.t. a conv kernel): rows = (tap, input channel) of

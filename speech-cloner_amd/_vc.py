@@ -103,7 +103,7 @@ class Gemm16Desc(C.Structure):
     _fields_ = [('d_X16', C.c_void_p), ('d_row_scale', C.c_void_p), ('M', C.c_int32), ('T', C.c_int32), ('C', C.c_int32),
                 ('ldx', C.c_int32), ('n_pairs', C.c_int32), ('ragged', C.c_int32), ('pairs', Gemm16Pair * 16),
                 ('d_col_scale', C.c_void_p), ('d_col_shift', C.c_void_p), ('d_C', C.c_void_p), ('ldc', C.c_int32),
-                ('accumulate', C.c_int32), ('atomic_splits', C.c_int32), ('d_workspace', C.c_void_p),
+                ('accumulate', C.c_int32), ('act', C.c_int32), ('atomic_splits', C.c_int32), ('d_workspace', C.c_void_p),
                 ('workspace_bytes', C.c_size_t)]
 
 

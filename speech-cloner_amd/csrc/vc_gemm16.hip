@@ -57,7 +57,7 @@ struct G16Args {
     const float* col_scale;
     const float* col_shift;
     float* Cout;
-    int32_t ldc, accumulate, n_pairs, ragged;
+    int32_t ldc, accumulate, n_pairs, ragged, act;
     int32_t zsplit;       // >= 1: blockIdx.z walks its own K range and ADDS its tile to Cout with float atomics (any pair count)
     int32_t xcd_tiles;
     int16_t seg_pair[8][4], seg_first[8][4], seg_count[8][4];
@@ -433,6 +433,10 @@ gemm16_kernel(G16Args a) {
                         o[1] = fmaf(acc[i][c][4 * q + 1] * rsc[i], sv.y, bv.y);
                         o[2] = fmaf(acc[i][c][4 * q + 2] * rsc[i], sv.z, bv.z);
                         o[3] = fmaf(acc[i][c][4 * q + 3] * rsc[i], sv.w, bv.w);
+                        if (a.act == VC_ACT_RELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.0f);
+                        }
                         *reinterpret_cast<f32x4v*>(smem + (i * 32 + li) * EP + chp * 4) = o;
                     }
                 }
@@ -836,6 +840,7 @@ int vc_gemm16(const vc_gemm16_desc* d, void* stream) {
                (d->ldx & 7) == 0, "vc_gemm16: bad shape M=%d T=%d C=%d ldx=%d", d->M, d->T, d->C, d->ldx);
     VC_REQUIRE(d->n_pairs >= 1 && d->n_pairs <= 16 && (d->ldc & 3) == 0, "vc_gemm16: bad pair count / ldc");
     const bool atomic = d->atomic_splits >= 1;
+    VC_REQUIRE(d->act == VC_ACT_NONE || (d->act == VC_ACT_RELU && !atomic), "vc_gemm16: act must be none or relu (none with atomic_splits)");
     VC_REQUIRE(d->atomic_splits >= 0 && d->atomic_splits <= MAX_SPLIT && !(atomic && (d->d_col_shift || d->ragged)),
                "vc_gemm16: atomic_splits 0..8, without col_shift / ragged");
     VC_REQUIRE((reinterpret_cast<uintptr_t>(d->d_X16) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->d_C) & 15) == 0, "vc_gemm16: unaligned");
@@ -849,7 +854,7 @@ int vc_gemm16(const vc_gemm16_desc* d, void* stream) {
     G16Args a{};
     a.X = d->d_X16; a.row_scale = d->d_row_scale; a.M = d->M; a.T = d->T; a.C = d->C; a.ldx = d->ldx;
     a.col_scale = d->d_col_scale; a.col_shift = d->d_col_shift; a.Cout = d->d_C; a.ldc = d->ldc; a.accumulate = d->accumulate;
-    a.n_pairs = d->n_pairs; a.ragged = d->ragged;
+    a.n_pairs = d->n_pairs; a.ragged = d->ragged; a.act = d->act;
     const int nsl = d->C >> 6;
     if (d->ragged) {
         // the bank data gradient: 128 input channels per bank, bank k = 1 .. C/128 with k taps, left padding k / 2

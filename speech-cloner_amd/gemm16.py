@@ -43,7 +43,7 @@ def transpose_split16(X, M, Cn, ldx, T, shift0=0, n_shifts=1, scale=None, shift=
 
 
 def gemm16(X16, rs, M, T, Cn, pairs, out, ldc, col_scale=None, col_shift=None, ragged=False, accumulate=False,
-           workspace=True, atomic_splits=0):
+           workspace=True, atomic_splits=0, act=0):
     """pairs: list of (Bt0, Bt1, taps0, extra, pad_l, c_off0, c_off1[, row0, nrows0, nrows1, s_off0, s_off1]) (ragged:
     taps / pad ignored).  ``workspace``: True = allocate what a split-K launch wants, False = none (one workgroup per
     row tile), or a uint8 tensor.  ``atomic_splits`` n >= 1: the weight-gradient form (include/vc_hip.h)."""
@@ -61,7 +61,7 @@ def gemm16(X16, rs, M, T, Cn, pairs, out, ldc, col_scale=None, col_shift=None, r
             p.row0, p.nrows0, p.nrows1, p.s_off0, p.s_off1 = pr[7:12]
     d.d_col_scale = col_scale.data_ptr() if col_scale is not None else None
     d.d_col_shift = col_shift.data_ptr() if col_shift is not None else None
-    d.d_C, d.ldc, d.accumulate, d.atomic_splits = out.data_ptr(), ldc, int(bool(accumulate)), int(atomic_splits)
+    d.d_C, d.ldc, d.accumulate, d.atomic_splits, d.act = out.data_ptr(), ldc, int(bool(accumulate)), int(atomic_splits), int(act)
     ws = None
     if atomic_splits:
         pass

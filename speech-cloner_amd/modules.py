@@ -414,6 +414,13 @@ def bn(inputs, is_training=True, activation_fn=None, scope="bn", reuse=None):
     return out
 
 
+def _f32_split_ok(store):
+    """float32 inference: the filter banks and the post-bank projection as three float16 MFMA products of exactly split
+    operands (gemm16.py / csrc/vc_gemm16.hip: the error against float64 equals the f32-MFMA kernels', at 2-3x their
+    rate).  vc_set_option('f32_f16x3', 0) keeps them on the f32-input MFMA kernels (A/B, tests)."""
+    return store.dtype == _torch().float32 and _vc.get_option('f32_f16x3') != 0
+
+
 def conv1d(inputs, filters=None, size=1, rate=1, padding="SAME", use_bias=False, activation_fn=None,
            scope="conv1d", reuse=None, bn_scope=None, residual=None, pool_input=False):
     """modules.py:104-140 (tf.layers.conv1d, stride 1, no bias).  Extra keyword arguments fuse
@@ -439,6 +446,21 @@ def conv1d(inputs, filters=None, size=1, rate=1, padding="SAME", use_bias=False,
         s, sh = _prep_bn(store, _scope(bn_scope), filters)
     out = torch.empty((N_, T_, filters), dtype=store.dtype, device=x.device)
     act = {None: _vc.ACT_NONE, 'relu': _vc.ACT_RELU}[activation_fn]
+    if _f32_split_ok(store) and residual is None and filters in (128, 256) and Cin % 64 == 0 and 1024 <= Cin <= 4096 and size <= 33:
+        # long-K projection (conv1d_1 behind the banks, modules.py:331-335): float32 result from float16 products
+        import gemm16
+        kscope = _scope(scope)
+
+        def build():
+            w16 = gemm16.Weights16(x.device)
+            pairs, cs = gemm16.conv_forward_operands(w16, store.vars[kscope + '/conv1d/kernel'])
+            w16.refresh()
+            return w16, pairs, (cs * s if s is not None else cs)
+        w16, pairs, scale = store.cached(('g16conv', kscope, bn_scope), build)
+        M = N_ * T_
+        x16, rs = gemm16.split16(x.contiguous().view(M, Cin), M, Cin, Cin, T_, pool=1 if pool_input else 0)
+        gemm16.gemm16(x16, rs, M, T_, Cin, pairs, out, filters, col_scale=scale, col_shift=sh, act=act)
+        return out
     gemm_launch(x, N_ * T_, T_, Cin, Cin, filters, [(bt, size * Cin, size, (size - 1) // 2, 0)], out, filters,
                 store.vc_dtype, pro_pool=int(pool_input), epi_scale=s, epi_shift=sh, act=act,
                 R=residual, ldr=filters if residual is not None else 0)
@@ -469,6 +491,23 @@ def conv1d_banks(inputs, K=16, embed_size=256, is_training=True, scope="conv1d_b
             groups.append((bt, k * Cin, k, (k - 1) // 2, F_ * (k - 1)))
         s, sh = _prep_bn(store, _scope('bn'), F_ * K)
     out = torch.empty((N_, T_, F_ * K), dtype=store.dtype, device=x.device)
+    if _f32_split_ok(store) and K % 2 == 0 and K <= 32 and Cin % 64 == 0 and F_ == BANK_FILTERS == 128:
+        # float32 result from float16 products; pairs of filter widths as in the bf16 bank kernel.  The pool stays with
+        # the next convolution's operand (pooled = False)
+        import gemm16
+        bscope = _scope(scope)
+
+        def build():
+            w16 = gemm16.Weights16(x.device)
+            kern = [store.vars[bscope + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k)) + '/conv1d/kernel'] for k in range(1, K + 1)]
+            pairs, cs = gemm16.bank_forward_operands(w16, kern, Cin)
+            w16.refresh()
+            return w16, pairs, cs * s
+        w16, pairs, scale = store.cached(('g16bank', bscope), build)
+        M = N_ * T_
+        x16, rs = gemm16.split16(x.contiguous().view(M, Cin), M, Cin, Cin, T_)
+        gemm16.gemm16(x16, rs, M, T_, Cin, pairs, out, F_ * K, col_scale=scale, col_shift=sh, act=_vc.ACT_RELU)
+        return (out, False) if pool_output == 'auto' else out
     d = gemm_desc(x, N_ * T_, T_, Cin, Cin, F_, groups, out, F_ * K, store.vc_dtype,
                   epi_scale=s, epi_shift=sh, act=_vc.ACT_RELU, epi_pool=1 if pool_output == 'auto' else 0)
     pooled = False

@@ -236,6 +236,33 @@ def test_weight_gradients_match_autograd(H, K):
     _check(dW1, ref1, 'projection filter gradient H=%d' % H)
 
 
+def test_f32_inference_blocks_on_the_split_path_agree_with_the_f32_mfma_kernels():
+    """float32 INFERENCE (modules.conv1d_banks / the post-bank conv1d with folded batch norm, relu and the pooled operand:
+    /root/reference/modules.py:144-166, 331-335) takes the split-float16 path by default; vc_set_option('f32_f16x3', 0)
+    keeps the f32-input MFMA kernels.  Same function, float32 accuracy both ways: the two agree to 6e-6 of the
+    tensor's maximum (at this K the f32-MFMA bank kernel alone measures 2.8e-6 from float64, the split path 1.1e-6:
+    test_bank_forward_pairs_match_float64)."""
+    import modules, _vc
+    N, T, H, K = 2, 400, 256, 32
+    x = _rand_acts(N, T, H, 50).cuda()
+    st = modules.VariableStore('float32')
+    outs = {}
+    for opt in (-1, 0):
+        with _vc.options(f32_f16x3=opt), modules.variable_store(st), modules.variable_scope('blk'):
+            b, pooled = modules.conv1d_banks(x, K=K, embed_size=256, is_training=False, pool_output='auto')
+            assert not pooled or opt == 0
+            y = modules.conv1d(b, filters=H, size=3, scope='conv1d_1', bn_scope='conv1d_1', activation_fn='relu',
+                               pool_input=0 if pooled else 2)
+        outs[opt] = (b, y, pooled)
+    assert ('g16bank', 'blk/conv1d_banks') in st._cache            # the split path ran and cached its operands
+    b1, y1, _ = outs[-1]
+    b0, y0, pooled0 = outs[0]
+    if not pooled0:
+        assert float((b1 - b0).abs().max() / b0.abs().max()) < 6e-6
+    assert float((y1 - y0).abs().max() / y0.abs().max()) < 6e-6
+    assert float(b1.min()) >= 0.0 and float(y1.min()) >= 0.0       # relu in the epilogue
+
+
 def test_bad_arguments_are_refused():
     import gemm16, _vc
     dev = torch.device('cuda')
