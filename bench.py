@@ -513,7 +513,8 @@ def train_measure(rank, world, steps, warmup):
         roof = {'kernel': 'gemm16_kernel (decoder step2 conv1d_banks forward: float32 convolution as 3 float16 MFMA products '
                           'of exactly split operands)', 'bound': 'mfma',
                 'achieved': round(ach, 2), 'peak': MFMA_F32_PEAK_TF, 'unit': 'TFLOP/s',
-                'frac': round(ach / MFMA_F32_PEAK_TF, 4), 'traffic': None,
+                'frac': round(ach / MFMA_F32_PEAK_TF, 4), 'traffic': _pmc_traffic('gemm16_bank_step2_train'),
+                'algorithmic_bytes_per_launch': M * H * 4 + 256 * 128 * 528 * 4 + M * 128 * K * 4,
                 'algorithmic_flop_per_launch': fl_bank, 'avg_kernel_ms': round(ms_bank, 4),
                 'executed': {'TFLOP/s': round(3 * ach, 1), 'peak': MFMA_BF16_PEAK_TF, 'frac': round(3 * ach / MFMA_BF16_PEAK_TF, 4),
                              'products_per_algorithmic_flop': 3},

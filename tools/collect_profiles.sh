@@ -20,6 +20,7 @@ for W in full frontend train vocoder; do
   timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$W -- python3 $R/bench.py --workload $W $EXTRA > $O/trace_$W.log 2>&1
   cp $O/trace_$W/*/*kernel_stats.csv $O/${W}_kernel_stats.csv 2>/dev/null
 done
+python3 $R/tools/train_timeline.py $O/trace_train/*/*kernel_trace.csv > $O/train_timeline.log 2>&1
 # the roofline kernel alone, >= 50 launches (bench.py's rocprof average mixes the step-1 and step-2 filter banks under one name)
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_bank -- python3 $R/tools/prof_kernels.py bank > $O/trace_bank.log 2>&1
 cp $O/trace_bank/*/*kernel_stats.csv $O/bank_step2_kernel_stats.csv 2>/dev/null
@@ -32,7 +33,8 @@ import csv, glob, collections, json
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 names = {'bank256_kernel': 'bank256_kernel_bf16_step2', 'conv256_kernel': 'conv256_kernel_bf16', 'gru_mfma_kernelILi256': 'gru_mfma_256',
          'gru_mfma_kernel<256>': 'gru_mfma_256', 'fe400_kernel<true>': 'fe400_stats_pass', 'fe400_kernel<false>': 'fe400_feature_pass', 'fe400_fused_kernel': 'fe400_one_launch',
-         'gl_iter400_kernel<false>': 'gl_iter400_kernel', 'cbhg_small_kernel': 'cbhg_small_kernel'}
+         'gl_iter400_kernel<false>': 'gl_iter400_kernel', 'cbhg_small_kernel': 'cbhg_small_kernel',
+         'gemm16_kernel': 'gemm16_bank_step2_train'}
 for f in glob.glob('$O/pmc_*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
         for k, v in names.items():
@@ -50,5 +52,9 @@ print(json.dumps({k: v.get('traffic_bytes_per_launch') for k, v in out.items()})
 PY
 cd $R
 timeout -k 10 200 python tools/fe_batch_sweep.py > $O/frontend_batch_sweep.log 2>&1
+# training convolutions on split-float16 operands: per-launch A/B against the f32-MFMA kernels, K-split forms, host enqueue time
+timeout -k 10 300 python tools/ab_gemm16.py > $O/ab_gemm16.log 2>&1
+timeout -k 10 300 python tools/ab_gemm16_split.py > $O/ab_gemm16_split.log 2>&1
+timeout -k 10 200 python tools/train_cpu_profile.py > $O/train_cpu_profile.log 2>&1
 rm -rf $O/trace_* $O/pmc_*/                  # keep the summaries (csv / json / logs), not the raw traces
 tail -2 $O/smoke.log; for f in bench_full bench_frontend bench_train bench_vocoder; do cut -c1-400 $O/$f.json; done

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Runs the dominant kernels of the hot path a few times each, stand-alone, so rocprofv3 (kernel
-trace or --pmc passes) sees clean dispatches:  python tools/prof_kernels.py [bank|proj1|gru|encfront|frontend|vocoder|all]
+trace or --pmc passes) sees clean dispatches:  python tools/prof_kernels.py [bank|proj1|gru|encfront|frontend|vocoder|train16|all]
 
 Shapes = the bench's full workload (64 windows x 400 frames, decoder step 2, bf16; front-end on
 32 x 4 s).  Prints the algorithmic bytes / FLOPs per launch used by bench.py's roofline."""
@@ -52,6 +52,22 @@ if what in ('vocoder', 'all'):
     amp = torch.rand(16, 1000, 201, device='cuda') * 0.1
     ph = torch.rand(16, 1000, 201, device='cuda') * 3.14159
     audio_lib.griffin_lim_batch(amp, None, 400, 80, num_iters=4, phase0=ph)
+if what in ('train16', 'all'):
+    # the training step's dominant launch: the step-2 filter bank forward at 32 x 400 frames on gemm16_kernel
+    import gemm16
+    Mt, Ht, Kt = 32 * T, 256, 32
+    gg = torch.Generator().manual_seed(3)
+    kern = [(torch.randn(k, Ht, 128, generator=gg) * 0.05).cuda() for k in range(1, Kt + 1)]
+    w16 = gemm16.Weights16(torch.device('cuda'))
+    pairs16, cs16 = gemm16.bank_forward_operands(w16, kern, Ht)
+    w16.refresh()
+    xt = torch.randn(Mt, Ht, device='cuda')
+    x16, rs16 = gemm16.split16(xt, Mt, Ht, Ht, T)
+    zt = torch.empty((Mt, 128 * Kt), device='cuda')
+    for _ in range(reps if what == 'all' else 60):
+        gemm16.gemm16(x16, rs16, Mt, T, Ht, pairs16, zt, 128 * Kt, col_scale=cs16)
+    print('train16: %.4g algorithmic FLOP/launch (x3 executed); operands: X16 %d B + W16 %d B, out %d B' % (
+        2.0 * 256 * 128 * 528 * Mt, Mt * 512 * 2, 256 * 128 * 528 * 2 * 2, Mt * 4096 * 4))
 torch.cuda.synchronize()
 print('bank  : %.4g FLOP/launch ; operands: X %d B + W %d B, out %d B' % (
     2.0 * 256 * 128 * 528 * W * T, W * T * 256 * 2, 256 * 128 * 528 * 2, W * T * 4096 * 2))
