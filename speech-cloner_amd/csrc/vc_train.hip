@@ -89,7 +89,8 @@ affine_act_kernel(const float* X, const float* scale, const float* shift, int re
 //           dA[t] = G[t]*[t==T-1 or A[t] >= A[t+1]] + G[t-1]*[t>0 and A[t] > A[t-1]],  dBN = dA*[A>0]
 // The routing decisions of modes 1 / 2 for element (row, c): bit 0: bn(X) > 0 (relu passes), bit 1: the element
 // takes G[t] (it is the pool winner of its own frame), bit 2: it takes G[t-1] (winner of the previous frame's pool).
-// bn_upstream and vc_bn_post_routing (the export the parity tests hand to the oracle) both go through this.
+// vc_bn_post_routing (the export the parity tests hand to the oracle) goes through this; bn_bwd_pass_kernel takes the same
+// decisions from the same float32 expressions, with the neighbouring frames' values kept in registers.
 __device__ __forceinline__ int bn_route(const float* X, int ld, size_t i, int t, int T, float sc, float sh) {
     const float a = fmaxf(X[i] * sc + sh, 0.0f);
     if (!(a > 0.0f)) return 0;
@@ -106,18 +107,6 @@ __device__ __forceinline__ int bn_route(const float* X, int ld, size_t i, int t,
     return bits;
 }
 
-__device__ __forceinline__ float bn_upstream(const float* G, const float* X, int ld, size_t row, int c, int t, int T,
-                                             float sc, float sh, int mode) {
-    const size_t i = row * ld + c;
-    if (mode == 0) return G[i];
-    if (mode == 1) return fmaxf(X[i] * sc + sh, 0.0f) > 0.0f ? G[i] : 0.0f;
-    const int bits = bn_route(X, ld, i, t, T, sc, sh);
-    float g = 0.0f;
-    if (bits & 2) g += G[i];
-    if (bits & 4) g += G[i - ld];
-    return g;
-}
-
 __global__ void __launch_bounds__(TB)
 bn_routing_kernel(const float* X, int M, int C, int ld, int T, const float* scale, const float* shift, unsigned char* out) {
     const size_t n = (size_t)M * C;
@@ -130,24 +119,75 @@ bn_routing_kernel(const float* X, int M, int C, int ld, int T, const float* scal
     }
 }
 
-// partial column sums of dBN and dBN * xhat
+// One pass over a block of rows, one thread per channel (coalesced 4-byte columns), every element of G and X read ONCE:
+// the relu / pool routing of mode 2 needs the activations of the neighbouring frames and the previous frame's gradient,
+// which a thread walking down its column keeps in registers (bn_route's decisions, computed from the same float32
+// expressions).  APPLY = false: partial column sums of dBN and dBN * xhat; APPLY = true: dX = gamma * rstd * (dBN -
+// dbeta / M - xhat * dgamma / M).
+template <bool APPLY>
 __global__ void __launch_bounds__(TB)
-bn_bwd_partial_kernel(const float* G, const float* X, int M, int C, int ld, int T, const float* scale,
-                      const float* shift, const float* mean, const float* rstd, int mode, int rows_per_blk,
-                      float* part) {
+bn_bwd_pass_kernel(const float* __restrict__ G, const float* __restrict__ X, int M, int C, int ld, int T,
+                   const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                   const float* __restrict__ rstd, int mode, int rows_per_blk, float* __restrict__ part,
+                   const float* __restrict__ gamma, const float* __restrict__ dbeta, const float* __restrict__ dgamma,
+                   float* __restrict__ dX) {
     const int c = blockIdx.x * TB + threadIdx.x;
     if (c >= C) return;
     const int r0 = blockIdx.y * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
+    if (r0 >= r1) return;
     const float sc = scale[c], sh = shift[c], mu = mean[c], rs = rstd[c];
-    float s = 0.0f, q = 0.0f;
-    for (int r = r0; r < r1; ++r) {
-        const float d = bn_upstream(G, X, ld, r, c, r % T, T, sc, sh, mode);
-        const float xh = (X[(size_t)r * ld + c] - mu) * rs;
-        s += d;
-        q = fmaf(d, xh, q);
+    float k0 = 0.0f, k1 = 0.0f, k2 = 0.0f;
+    if (APPLY) {
+        const float invM = 1.0f / (float)M;
+        k0 = gamma[c] * rs; k1 = dbeta[c] * invM; k2 = dgamma[c] * invM;
     }
-    part[((size_t)blockIdx.y * 2 + 0) * C + c] = s;
-    part[((size_t)blockIdx.y * 2 + 1) * C + c] = q;
+    float s = 0.0f, q = 0.0f;
+    int t = r0 % T;
+    const float* xp = X + (size_t)r0 * ld + c;
+    const float* gp = G + (size_t)r0 * ld + c;
+    float x_cur = xp[0];
+    float a_prev = 0.0f, g_prev = 0.0f;
+    if (mode == 2 && t > 0) {
+        a_prev = fmaxf(xp[-ld] * sc + sh, 0.0f);
+        g_prev = gp[-ld];
+    }
+    for (int r = r0; r < r1; ++r) {
+        const float g_cur = gp[0];
+        const bool has_next = r + 1 < M;                 // (a window's last frame never looks at it)
+        const float x_next = has_next ? xp[ld] : 0.0f;
+        float d;
+        if (mode == 0) {
+            d = g_cur;
+        } else {
+            const float a = fmaxf(x_cur * sc + sh, 0.0f);
+            if (mode == 1) {
+                d = a > 0.0f ? g_cur : 0.0f;
+            } else {
+                d = 0.0f;
+                if (a > 0.0f) {
+                    const float an = fmaxf(x_next * sc + sh, 0.0f);
+                    if (t == T - 1 || a >= an) d += g_cur;
+                    if (t > 0 && a > a_prev) d += g_prev;
+                }
+                a_prev = a;
+                g_prev = g_cur;
+            }
+        }
+        const float xh = (x_cur - mu) * rs;
+        if (APPLY) {
+            dX[(size_t)r * ld + c] = k0 * (d - k1 - xh * k2);
+        } else {
+            s += d;
+            q = fmaf(d, xh, q);
+        }
+        x_cur = x_next;
+        xp += ld; gp += ld;
+        if (++t == T) t = 0;
+    }
+    if (!APPLY) {
+        part[((size_t)blockIdx.y * 2 + 0) * C + c] = s;
+        part[((size_t)blockIdx.y * 2 + 1) * C + c] = q;
+    }
 }
 
 // reduce partials -> dbeta, dgamma ; dX = gamma*rstd*(dBN - dbeta/M - xhat*dgamma/M)
@@ -162,23 +202,6 @@ bn_bwd_reduce_kernel(const float* part, int nblk, int C, float* dbeta, float* dg
     }
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
-}
-
-__global__ void __launch_bounds__(TB)
-bn_bwd_apply_kernel(const float* G, const float* X, int M, int C, int ld, int T, const float* gamma,
-                    const float* scale, const float* shift, const float* mean, const float* rstd,
-                    const float* dbeta, const float* dgamma, int mode, float* dX) {
-    const size_t n = (size_t)M * C;
-    size_t i = (size_t)blockIdx.x * TB + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * TB;
-    const float invM = 1.0f / (float)M;
-    for (; i < n; i += stride) {
-        const size_t r = i / C;
-        const int c = (int)(i - r * C);
-        const float d = bn_upstream(G, X, ld, r, c, (int)(r % T), T, scale[c], shift[c], mode);
-        const float xh = (X[r * ld + c] - mean[c]) * rstd[c];
-        dX[r * ld + c] = gamma[c] * rstd[c] * (d - dbeta[c] * invM - xh * dgamma[c] * invM);
-    }
 }
 
 // ---------------------------------------------------------------------------- relu/dropout bwd
@@ -1246,11 +1269,12 @@ int vc_bn_backward(const float* d_G, const float* d_X, int32_t M, int32_t C, int
     VC_REQUIRE(M > 0 && C > 0 && ld >= C && T > 0 && M % T == 0 && mode >= 0 && mode <= 2, "bad shape/mode");
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int rows = BN_ROWS, nblk = (M + rows - 1) / rows;
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3((C + TB - 1) / TB, nblk), dim3(TB), 0, st, d_G, d_X, M, C, ld, T, d_scale,
-                       d_shift, d_mean, d_rstd, mode, rows, d_workspace);
+    const dim3 grid((C + TB - 1) / TB, nblk);
+    hipLaunchKernelGGL(bn_bwd_pass_kernel<false>, grid, dim3(TB), 0, st, d_G, d_X, M, C, ld, T, d_scale, d_shift, d_mean, d_rstd,
+                       mode, rows, d_workspace, d_gamma, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + TB - 1) / TB), dim3(TB), 0, st, d_workspace, nblk, C, d_dbeta, d_dgamma);
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nblocks((size_t)M * C)), dim3(TB), 0, st, d_G, d_X, M, C, ld, T, d_gamma,
-                       d_scale, d_shift, d_mean, d_rstd, d_dbeta, d_dgamma, mode, d_dX);
+    hipLaunchKernelGGL(bn_bwd_pass_kernel<true>, grid, dim3(TB), 0, st, d_G, d_X, M, C, ld, T, d_scale, d_shift, d_mean, d_rstd,
+                       mode, rows, (float*)nullptr, d_gamma, (const float*)d_dbeta, (const float*)d_dgamma, d_dX);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }
