@@ -36,6 +36,30 @@ col_stats_partial_kernel(const float* X, int M, int C, int ld, int rows_per_blk,
     part[((size_t)blockIdx.y * 2 + 1) * C + c] = q;
 }
 
+// Column sums over `nblk` rows of per-block partials, two interleaved quantities per block (rows 2b, 2b + 1 of `part`;
+// NQ = 1: one quantity, rows b): 256 threads = 32 channels x 8 row segments, double accumulation in a fixed order.  One
+// thread per channel walking all the partials was a 200-deep chain of dependent loads: 55-72 us per call, six calls on
+// the critical path of a training step.  Results land in lanes with seg == 0 (returns false elsewhere).
+template <int NQ>
+__device__ __forceinline__ bool sum_partials(const float* __restrict__ part, int nblk, int C, int& c, double& s, double& q) {
+    __shared__ double sh[2][8][33];
+    const int cl = threadIdx.x & 31, seg = threadIdx.x >> 5;
+    c = blockIdx.x * 32 + cl;
+    s = 0.0; q = 0.0;
+    if (c < C)
+        for (int b = seg; b < nblk; b += 8) {
+            s += (double)part[((size_t)b * NQ + 0) * C + c];
+            if (NQ == 2) q += (double)part[((size_t)b * NQ + 1) * C + c];
+        }
+    sh[0][seg][cl] = s;
+    sh[1][seg][cl] = q;
+    __syncthreads();
+    if (seg != 0 || c >= C) return false;
+#pragma unroll
+    for (int k = 1; k < 8; ++k) { s += sh[0][k][cl]; q += sh[1][k][cl]; }
+    return true;
+}
+
 // Train-mode batch norm bookkeeping: batch mean / biased variance -> scale, shift for the
 // consumer's prologue, saved mean / rstd for backward, moving statistics updated in place with
 // the Bessel-corrected variance (tf.nn.fused_batch_norm semantics), decay 0.999, eps 1e-3.
@@ -43,13 +67,9 @@ __global__ void __launch_bounds__(TB)
 bn_train_finalize_kernel(const float* part, int nblk, int M, int C, const float* gamma, const float* beta,
                          float* moving_mean, float* moving_var, float decay, float eps,
                          float* scale, float* shift, float* mean_out, float* rstd_out) {
-    const int c = blockIdx.x * TB + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += (double)part[((size_t)b * 2 + 0) * C + c];
-        q += (double)part[((size_t)b * 2 + 1) * C + c];
-    }
+    int c;
+    double s, q;
+    if (!sum_partials<2>(part, nblk, C, c, s, q)) return;
     const double mean = s / M;
     double var = q / M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -193,13 +213,9 @@ bn_bwd_pass_kernel(const float* __restrict__ G, const float* __restrict__ X, int
 // reduce partials -> dbeta, dgamma ; dX = gamma*rstd*(dBN - dbeta/M - xhat*dgamma/M)
 __global__ void __launch_bounds__(TB)
 bn_bwd_reduce_kernel(const float* part, int nblk, int C, float* dbeta, float* dgamma) {
-    const int c = blockIdx.x * TB + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, q = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += (double)part[((size_t)b * 2 + 0) * C + c];
-        q += (double)part[((size_t)b * 2 + 1) * C + c];
-    }
+    int c;
+    double s, q;
+    if (!sum_partials<2>(part, nblk, C, c, s, q)) return;
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
 }
@@ -332,10 +348,9 @@ col_sum_partial_kernel(const float* X, int M, int C, int ld, int nrb, float* par
 }
 __global__ void __launch_bounds__(TB)
 col_sum_final_kernel(const float* part, int nrb, int C, float* out, int accumulate) {
-    const int c = blockIdx.x * TB + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0;
-    for (int b = 0; b < nrb; ++b) s += (double)part[(size_t)b * C + c];
+    int c;
+    double s, q;
+    if (!sum_partials<1>(part, nrb, C, c, s, q)) return;
     out[c] = (accumulate ? out[c] : 0.0f) + (float)s;
 }
 
@@ -1246,7 +1261,7 @@ int vc_bn_train_stats(const float* d_X, int32_t M, int32_t C, int32_t ld, const 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int rows = BN_ROWS, nblk = (M + rows - 1) / rows;
     hipLaunchKernelGGL(col_stats_partial_kernel, dim3((C + TB - 1) / TB, nblk), dim3(TB), 0, st, d_X, M, C, ld, rows, d_workspace);
-    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((C + TB - 1) / TB), dim3(TB), 0, st, d_workspace, nblk, M, C, d_gamma,
+    hipLaunchKernelGGL(bn_train_finalize_kernel, dim3((C + 31) / 32), dim3(TB), 0, st, d_workspace, nblk, M, C, d_gamma,
                        d_beta, d_moving_mean, d_moving_var, decay, eps, d_scale, d_shift, d_mean, d_rstd);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
@@ -1272,7 +1287,7 @@ int vc_bn_backward(const float* d_G, const float* d_X, int32_t M, int32_t C, int
     const dim3 grid((C + TB - 1) / TB, nblk);
     hipLaunchKernelGGL(bn_bwd_pass_kernel<false>, grid, dim3(TB), 0, st, d_G, d_X, M, C, ld, T, d_scale, d_shift, d_mean, d_rstd,
                        mode, rows, d_workspace, d_gamma, (const float*)nullptr, (const float*)nullptr, (float*)nullptr);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + TB - 1) / TB), dim3(TB), 0, st, d_workspace, nblk, C, d_dbeta, d_dgamma);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((C + 31) / 32), dim3(TB), 0, st, d_workspace, nblk, C, d_dbeta, d_dgamma);
     hipLaunchKernelGGL(bn_bwd_pass_kernel<true>, grid, dim3(TB), 0, st, d_G, d_X, M, C, ld, T, d_scale, d_shift, d_mean, d_rstd,
                        mode, rows, (float*)nullptr, d_gamma, (const float*)d_dbeta, (const float*)d_dgamma, d_dX);
     VC_HIP_CHECK(hipGetLastError());
@@ -1326,7 +1341,7 @@ int vc_col_sum(const float* d_X, int32_t M, int32_t C, int32_t ld, float* d_out,
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nrb = 64;                                   // workspace: 64 * C floats
     hipLaunchKernelGGL(col_sum_partial_kernel, dim3((C + 63) / 64, nrb), dim3(TB), 0, st, d_X, M, C, ld, nrb, d_workspace);
-    hipLaunchKernelGGL(col_sum_final_kernel, dim3((C + TB - 1) / TB), dim3(TB), 0, st, d_workspace, nrb, C, d_out, accumulate);
+    hipLaunchKernelGGL(col_sum_final_kernel, dim3((C + 31) / 32), dim3(TB), 0, st, d_workspace, nrb, C, d_out, accumulate);
     VC_HIP_CHECK(hipGetLastError());
     return VC_OK;
 }
