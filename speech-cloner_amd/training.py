@@ -57,13 +57,17 @@ class _Ops:
     # the main stream had queued when they were issued, and fill the CUs the latency-bound recurrence kernels leave
     # idle.  StageTrainer sets / joins it; None = everything on the current stream.
     side_stream = None
+    # A second one for the SMALL optimiser-only jobs (recurrence and highway weight gradients): behind the multi-millisecond
+    # filter-gradient launches of the first they would start late, and the main stream was seen to stall at the point
+    # where it hands work to a backlogged stream until that stream had nearly caught up (train_timeline.log).
+    side_stream2 = None
 
     @staticmethod
     @contextlib.contextmanager
-    def side(*inputs):
+    def side(*inputs, small=False):
         """Run the body on the side stream (if any), ordered behind the current stream's queue; `inputs` are tensors of
         the current stream that the body reads or writes (kept alive for the side stream)."""
-        ws = _Ops.side_stream
+        ws = _Ops.side_stream2 if (small and _Ops.side_stream2 is not None) else _Ops.side_stream
         if ws is None:
             yield
             return
@@ -175,6 +179,7 @@ class StageTrainer:
         self.keep = 1.0 - float(c['dropout_rate'])
         self.loss_ws = torch.empty(256, dtype=torch.float32, device=dev)
         self._side = torch.cuda.Stream(device=dev) if torch.cuda.is_available() else None    # weight gradients (_Ops.side)
+        self._side2 = torch.cuda.Stream(device=dev) if torch.cuda.is_available() else None   # the small ones (_Ops.side_stream2)
         self._pending = []                           # gradient buckets already being all-reduced (data parallel)
         self.overlap_allreduce = True                # False: one blocking all-reduce in apply_gradients (tests)
         self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
@@ -510,8 +515,8 @@ class StageTrainer:
         dYn = self._dgrad_dense(dpre, 6 * H, 6 * H, sv['btx'].t().contiguous(), M, T_)
         # ... then the weight gradients, one stretch of the side stream
         Yn = sv['Ys'][-1]
-        with _Ops.side(dpre, Yn, sv['G'], sv['rh']):
-            inner, _Ops.side_stream = _Ops.side_stream, None              # already there: the wrappers must not re-enter
+        with _Ops.side(dpre, Yn, sv['G'], sv['rh'], small=True):
+            inner, _Ops.side_stream, _Ops.side_stream2 = (_Ops.side_stream, _Ops.side_stream2), None, None    # already there: no re-entry
             try:
                 dbx = torch.empty(6 * H, dtype=torch.float32, device=dev)
                 _Ops.col_sum(dpre, M, 6 * H, 6 * H, dbx)
@@ -536,7 +541,7 @@ class StageTrainer:
                     _Ops.wgrad(RT, ldr, H, M, T_, dpT, ldp, [(d * 3 * H + 2 * H, H, 1, 0, ck[H:], H)])
                 del dpT, YT, HpT, RT, dbx
             finally:
-                _Ops.side_stream = inner
+                _Ops.side_stream, _Ops.side_stream2 = inner
         return dYn
 
     def _stage_backward_front(self, s, sv, dYc, need_dx):
@@ -568,40 +573,41 @@ class StageTrainer:
             dYc = self._dgrad_dense(dp, NP, NP, bt.t().contiguous(), M, T_, R=dXd)
             side_jobs.append((hs, Xi, dp, NP))
             del pre, dp
-        # ... then everything only the optimiser needs, for ALL the blocks as one stretch of the side stream (one
-        # cross-stream dependency for the chain instead of several per block: the main stream ran at most ~3 blocks
-        # ahead of the side stream's backlog otherwise and sat idle for the rest)
-        if side_jobs:
-            with _Ops.side(*[t for job in side_jobs for t in job[1:3]]):
-                inner, _Ops.side_stream = _Ops.side_stream, None          # already there: the wrappers must not re-enter
-                try:
-                    for hs, Xi, dp, NP in side_jobs:
-                        g1, g2 = self.g(hs + '/dense1/kernel'), self.g(hs + '/dense2/kernel')
-                        b1, b2 = self.g(hs + '/dense1/bias'), self.g(hs + '/dense2/bias')
-                        grp = []
-                        for q in range((H + 31) // 32):
-                            n = min(32, H - 32 * q)
-                            grp.append((64 * q, n, 1, 0, g1[:, 32 * q:], H))
-                            grp.append((64 * q + 32, n, 1, 0, g2[:, 32 * q:], H))
-                        XT, ldx = _Ops.transpose(Xi, M, H, H, T_)
-                        dpT, ldp = _Ops.transpose(dp, M, NP, NP, T_)
-                        dbp = torch.empty(NP, dtype=torch.float32, device=dev)
-                        _Ops.col_sum(dp, M, NP, NP, dbp)
-                        if H % 32 == 0:    # paired order [32 x dense1 | 32 x dense2] per 32 units -> the two bias vectors: two strided copies
-                            pr = dbp.view(H // 32, 2, 32)
-                            b1.view(H // 32, 32).copy_(pr[:, 0])
-                            b2.view(H // 32, 32).copy_(pr[:, 1])
-                        else:
+        def flush_highway_side():
+            # ... then everything only the optimiser needs, for ALL the blocks as one stretch of the side stream (one
+            # cross-stream dependency for the chain instead of several per block: the main stream ran at most ~3 blocks
+            # ahead of the side stream's backlog otherwise and sat idle for the rest)
+            if side_jobs:
+                with _Ops.side(*[t for job in side_jobs for t in job[1:3]], small=True):
+                    inner, _Ops.side_stream, _Ops.side_stream2 = (_Ops.side_stream, _Ops.side_stream2), None, None    # already there: no re-entry
+                    try:
+                        for hs, Xi, dp, NP in side_jobs:
+                            g1, g2 = self.g(hs + '/dense1/kernel'), self.g(hs + '/dense2/kernel')
+                            b1, b2 = self.g(hs + '/dense1/bias'), self.g(hs + '/dense2/bias')
+                            grp = []
                             for q in range((H + 31) // 32):
                                 n = min(32, H - 32 * q)
-                                b1[32 * q:32 * q + n].copy_(dbp[64 * q:64 * q + n])
-                                b2[32 * q:32 * q + n].copy_(dbp[64 * q + 32:64 * q + 32 + n])
-                        for j in range(0, len(grp), 32):
-                            _Ops.wgrad(XT, ldx, H, M, T_, dpT, ldp, grp[j:j + 32])
-                        del XT, dpT, dbp
-                finally:
-                    _Ops.side_stream = inner
-            del side_jobs
+                                grp.append((64 * q, n, 1, 0, g1[:, 32 * q:], H))
+                                grp.append((64 * q + 32, n, 1, 0, g2[:, 32 * q:], H))
+                            XT, ldx = _Ops.transpose(Xi, M, H, H, T_)
+                            dpT, ldp = _Ops.transpose(dp, M, NP, NP, T_)
+                            dbp = torch.empty(NP, dtype=torch.float32, device=dev)
+                            _Ops.col_sum(dp, M, NP, NP, dbp)
+                            if H % 32 == 0:    # paired order [32 x dense1 | 32 x dense2] per 32 units -> the two bias vectors: two strided copies
+                                pr = dbp.view(H // 32, 2, 32)
+                                b1.view(H // 32, 32).copy_(pr[:, 0])
+                                b2.view(H // 32, 32).copy_(pr[:, 1])
+                            else:
+                                for q in range((H + 31) // 32):
+                                    n = min(32, H - 32 * q)
+                                    b1[32 * q:32 * q + n].copy_(dbp[64 * q:64 * q + n])
+                                    b2[32 * q:32 * q + n].copy_(dbp[64 * q + 32:64 * q + 32 + n])
+                            for j in range(0, len(grp), 32):
+                                _Ops.wgrad(XT, ldx, H, M, T_, dpT, ldp, grp[j:j + 32])
+                            del XT, dpT, dbp
+                    finally:
+                        _Ops.side_stream, _Ops.side_stream2 = inner
+                side_jobs.clear()
 
         # ---- Y0 = bn2(Q2) + D2
         p2 = s + '/CBHG/conv1d_2'
@@ -699,6 +705,7 @@ class StageTrainer:
                             out_f32=True)
         del dZb
 
+        flush_highway_side()
         # ---- prenet
         pn = s + '/prenet'
         D1, D2, X0 = sv['D1'], sv['D2'], sv['X0']
@@ -731,6 +738,7 @@ class StageTrainer:
         """The current stream waits for everything this trainer issued to its side stream."""
         if self._side is not None:
             _torch().cuda.current_stream().wait_stream(self._side)
+            _torch().cuda.current_stream().wait_stream(self._side2)
 
     def _drain_pending(self):
         """Buckets of an earlier forward_backward that no apply_gradients consumed (gradient accumulation, a retry
@@ -756,7 +764,9 @@ class StageTrainer:
         if not self.overlap_allreduce or not (torch.distributed.is_available() and torch.distributed.is_initialized()) \
                 or torch.distributed.get_world_size() < 2:
             return
-        with _Ops.side():        # behind the main stream's queue AND the weight gradients issued to the side stream so far
+        if _Ops.side_stream is not None and _Ops.side_stream2 is not None:
+            _Ops.side_stream.wait_stream(_Ops.side_stream2)            # the small weight gradients of the bucket too
+        with _Ops.side():        # behind the main stream's queue AND the weight gradients issued to the side streams so far
             self._pending.append((lo, hi, torch.distributed.all_reduce(self.grad[lo:hi], op=torch.distributed.ReduceOp.SUM,
                                                                         async_op=True)))
 
@@ -893,7 +903,7 @@ class DecoderTrainer(StageTrainer):
                 lm, ls = (float(v) for v in self.losses.cpu())
                 dY1.mul_(1.0 / lm)
                 dY2.mul_(1.0 / ls)
-            _Ops.side_stream = self._side             # weight gradients leave the critical path (see _Ops.side)
+            _Ops.side_stream, _Ops.side_stream2 = self._side, self._side2    # weight gradients leave the critical path (see _Ops.side)
             try:
                 dX2 = self._stage_backward(s2, sv2, dY2, need_dx=True)
                 del sv2
@@ -906,7 +916,7 @@ class DecoderTrainer(StageTrainer):
                 self._stage_backward(s1, sv1, dY1, need_dx=False)
                 self._start_allreduce(*self._slice_of(s1 + '/'))
             finally:
-                _Ops.side_stream = None
+                _Ops.side_stream = _Ops.side_stream2 = None
                 self._join_side()                     # whoever reads the gradient arena next finds it complete (also
                                                       # after an exception: nothing keeps writing the arena)
         return self.losses
@@ -939,10 +949,10 @@ class EncoderTrainer(StageTrainer):
             ws = torch.empty(3 * M, dtype=torch.float32, device=x.device)
             _vc.check(_lib().vc_softmax_ce(_p(y), _p(target), M, n_out, y.shape[1], _p(dY), y.shape[1], _p(out3), _p(ws), _st()))
             if backward:
-                _Ops.side_stream = self._side
+                _Ops.side_stream, _Ops.side_stream2 = self._side, self._side2
                 try:
                     self._stage_backward(enc._scope, sv, dY, need_dx=False)
                 finally:
-                    _Ops.side_stream = None
+                    _Ops.side_stream = _Ops.side_stream2 = None
                     self._join_side()
         return out3

@@ -48,3 +48,14 @@ torch.cuda.synchronize()
 s = io.StringIO()
 pstats.Stats(pr, stream=s).sort_stats('cumulative').print_stats(28)
 print(s.getvalue()[:6000])
+# device allocations per step: a steady-state step should be served from the caching allocator (hipMalloc / hipFree block
+# the host and synchronise the device)
+for i in range(3):
+    a = torch.cuda.memory_stats()
+    tr.forward_backward(mfcc, mel, stft)
+    tr.apply_gradients(1)
+    torch.cuda.synchronize()
+    b = torch.cuda.memory_stats()
+    print('step %d: hipMalloc calls %d, hipFree calls %d, allocator retries %d, reserved %.2f GB, peak allocated %.2f GB' % (
+        i, b['num_device_alloc'] - a['num_device_alloc'], b['num_device_free'] - a['num_device_free'],
+        b['num_alloc_retries'] - a['num_alloc_retries'], b['reserved_bytes.all.current'] / 1e9, b['allocated_bytes.all.peak'] / 1e9))

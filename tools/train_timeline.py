@@ -38,3 +38,10 @@ gaps = [((main[i + 1][1] - main[i][2]) / 1e6, i) for i in range(len(main) - 1)]
 print('main stream %s: busy %.2f ms, idle %.2f ms' % (main_id, sum(r[2] - r[1] for r in main) / 1e6, sum(g for g, _ in gaps if g > 0)))
 for g, i in sorted(gaps, reverse=True)[:8]:
     print('  idle %.3f ms at %.2f, after %s, before %s' % (g, (main[i][2] - t0) / 1e6, short(main[i][0]), short(main[i + 1][0])))
+if len(sys.argv) > 2 and sys.argv[2] == 'gap':
+    g, i = sorted(gaps, reverse=True)[0]
+    lo, hi = main[i][2] - 400000, main[i + 1][1] + 300000
+    print('around the longest idle stretch of the main stream:')
+    for r in step:
+        if r[2] >= lo and r[1] <= hi:
+            print('  %8.3f +%6.3f  s%s  %s' % ((r[1] - t0) / 1e6, (r[2] - r[1]) / 1e6, r[3], short(r[0])))
