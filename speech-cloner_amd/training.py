@@ -319,10 +319,6 @@ class StageTrainer:
         # conv banks: raw outputs, batch statistics (modules.py:144-166, is_training)
         CB = BANK_FILTERS * K
         b = s + '/CBHG/conv1d_banks'
-        groups = []
-        for k in range(1, K + 1):
-            sub = b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k))
-            groups.append((modules._prep_conv(st, sub, k, H, BANK_FILTERS), k * H, k, (k - 1) // 2, BANK_FILTERS * (k - 1)))
         Zb = torch.empty((M, CB), dtype=torch.float32, device=dev)
         g16 = self._g16_plan(s, H, K, M, T_)
         sv['g16'] = g16
@@ -331,6 +327,10 @@ class StageTrainer:
             gemm16.gemm16(d16, drs, M, T_, H, g16['bank_fwd'][0], Zb, CB, col_scale=g16['bank_fwd'][1])
             del d16, drs
         else:
+            groups = []        # (float32 kernel layouts: built -- and re-laid out after every update -- only on this path)
+            for k in range(1, K + 1):
+                sub = b + ('/conv1d' if k == 1 else '/num_{}/conv1d'.format(k))
+                groups.append((modules._prep_conv(st, sub, k, H, BANK_FILTERS), k * H, k, (k - 1) // 2, BANK_FILTERS * (k - 1)))
             gemm_launch(D2, M, T_, H, H, BANK_FILTERS, groups, Zb, CB, f32, out_f32=True)
         sb = _Ops.bn_stats(Zb, M, CB, self.w(b + '/bn/gamma'), self.w(b + '/bn/beta'),
                            self.w(b + '/bn/moving_mean'), self.w(b + '/bn/moving_variance'))
