@@ -263,6 +263,50 @@ def test_f32_inference_blocks_on_the_split_path_agree_with_the_f32_mfma_kernels(
     assert float(b1.min()) >= 0.0 and float(y1.min()) >= 0.0       # relu in the epilogue
 
 
+@pytest.mark.parametrize('H,K,N,T', [(64, 4, 5, 24), (192, 6, 3, 100), (256, 32, 7, 20), (128, 2, 1, 400)])
+def test_odd_shapes_match_float64(H, K, N, T):
+    """Shapes the shipped configuration never produces but the trainer would hand over (any H % 64 == 0, even K <= 32):
+    fewer rows than one 256-row tile, windows shorter than the widest filter (every tap of it masked somewhere), one
+    channel slab, a single window.  Forward, the projection's data gradient, and -- where the trainer uses it -- the
+    bank's data gradient, against float64."""
+    import gemm16
+    M, CB = N * T, 128 * K
+    g = torch.Generator().manual_seed(1000 + H + K)
+    x = _rand_acts(N, T, H, 60 + K)
+    Ws = [(torch.randn(k, H, 128, generator=g) * (0.3 / (k * H) ** 0.5)).float() for k in range(1, K + 1)]
+    W1 = (torch.randn(3, CB, H, generator=g) * 0.05).float()
+    dev = torch.device('cuda')
+    w16 = gemm16.Weights16(dev)
+    Wd = [W.to(dev) for W in Ws]
+    fp, fcs = gemm16.bank_forward_operands(w16, Wd, H)
+    dp, dcs = gemm16.conv_dgrad_operands(w16, W1.to(dev))
+    if H in (128, 256):
+        bp, bcs = gemm16.bank_dgrad_operands(w16, Wd, H)
+    w16.refresh()
+    # forward
+    ref = torch.cat([_conv_same64(x.double(), W.double()) for W in Ws], dim=2).reshape(M, CB)
+    x16, rs = gemm16.split16(x.to(dev).view(M, H), M, H, H, T)
+    out = torch.full((M, CB), float('nan'), device=dev)
+    gemm16.gemm16(x16, rs, M, T, H, fp, out, CB, col_scale=fcs)
+    _check(out, ref, 'odd shape forward H=%d K=%d N=%d T=%d' % (H, K, N, T))
+    # projection data gradient
+    dq = _rand_acts(N, T, H, 61)
+    p = torch.zeros(N, T, CB, dtype=torch.float64, requires_grad=True)
+    (refp,) = torch.autograd.grad(_conv_same64(p, W1.double()), p, dq.double())
+    q16, qrs = gemm16.split16(dq.to(dev).view(M, H), M, H, H, T)
+    outp = torch.full((M, CB), float('nan'), device=dev)
+    gemm16.gemm16(q16, qrs, M, T, H, dp, outp, CB, col_scale=dcs)
+    _check(outp, refp.reshape(M, CB), 'odd shape projection data gradient')
+    if H in (128, 256):
+        dz = _rand_acts(N, T, CB, 62)
+        xx = torch.zeros(N, T, H, dtype=torch.float64, requires_grad=True)
+        (refb,) = torch.autograd.grad(torch.cat([_conv_same64(xx, W.double()) for W in Ws], dim=2), xx, dz.double())
+        z16, zrs = gemm16.split16(dz.to(dev).view(M, CB), M, CB, CB, T)
+        outb = torch.zeros((M, H), device=dev)
+        gemm16.gemm16(z16, zrs, M, T, CB, bp, outb, H, col_scale=bcs, ragged=True, accumulate=True)
+        _check(outb, refb.reshape(M, H), 'odd shape bank data gradient')
+
+
 def test_bad_arguments_are_refused():
     import gemm16, _vc
     dev = torch.device('cuda')
