@@ -115,6 +115,53 @@ def test_train_step_gradients_match_autograd(dropout, loss_type):
         assert np.abs(dec.store.vars[n].cpu().numpy() - v.numpy()).max() < 1e-5, n
 
 
+def test_train_step_on_the_split_float16_path_at_a_small_configuration():
+    """The same step with stage widths that put the filter bank and the first projection on the split-float16 path at
+    shapes far from the shipped ones (training._g16_plan: any H % 64 == 0 with an even K): stage 1 E = 128 -> H = 64 (bank
+    forward and the projection's data gradient only), stage 2 E = 256 -> H = 128 (all four forms, 128-column filters as
+    single-filter pairs), 4 and 6 banks, 160 frames in 4 windows of 40 (less than one 256-row tile; the filter
+    gradients stay on wgrad_kernel: the frame count is not a multiple of 64).  Against autograd on the f64 oracle with
+    the device's own relu / pool routing (see test_hp_size_train_step_matches_autograd: at 160 frames ONE relu decided
+    the other way moves a bias gradient by several per cent), every gradient element within 1e-4."""
+    cfg = _cfg(dropout=0.1)
+    cfg['steps_v'][0].update(embed_size=128, num_conv_banks=4)
+    cfg['steps_v'][1].update(embed_size=256, num_conv_banks=6)
+    dec, w, ppg, t_mel, t_stft = _setup(cfg)
+    tr = dec._get_trainer()
+    tr.export_routing = True
+    x = torch.from_numpy(ppg).cuda()
+    losses = tr.forward_backward(x, torch.from_numpy(t_mel).cuda(), torch.from_numpy(t_stft).cuda())
+    assert set(tr._g16) == {'decoder/step1', 'decoder/step2'}
+    assert 'bank_dgrad' not in tr._g16['decoder/step1'] and 'bank_dgrad' in tr._g16['decoder/step2']
+    routing = _device_routing(tr)
+    tr.export_routing = False
+    ml, sl, grads, stats, ym, ys = _oracle_step(cfg, w, ppg, t_mel, t_stft, tr.seed + 1000 * tr.step_count, routing=routing)
+    got = losses.cpu().numpy()
+    assert abs(got[0] - ml) < 1e-5 * max(1, ml) and abs(got[1] - sl) < 1e-5 * max(1, sl), (got, ml, sl)
+    assert np.abs(tr.y_mel.cpu().numpy().reshape(ym.shape) - ym).max() < 1e-4
+    assert np.abs(tr.y_stft.cpu().numpy().reshape(ys.shape) - ys).max() < 1e-4
+    worst = ('', 0.0)
+    for n in tr.names:
+        g = tr.g(n).cpu().numpy().astype(np.float64)
+        err = np.abs(g - grads[n]).max() / max(np.abs(grads[n]).max(), 1e-6)
+        if err > worst[1]:
+            worst = (n, err)
+    print('worst gradient mismatch %s %.3e' % worst)
+    assert worst[1] < 1e-4, 'worst gradient mismatch %s: %.3e' % worst
+    # a second step after Adam: the float16 weight copies were rewritten behind the update (their own stream), the
+    # forward pass waits for them -- the loss must move like the float32-MFMA path's does
+    tr.apply_gradients(1)
+    l2 = tr.forward_backward(x, torch.from_numpy(t_mel).cuda(), torch.from_numpy(t_stft).cuda()).cpu().numpy()
+    cfg32 = dict(cfg, train_f16x3=False)
+    dec32, _, _, _, _ = _setup(cfg32)
+    tr32 = dec32._get_trainer()
+    tr32.forward_backward(x, torch.from_numpy(t_mel).cuda(), torch.from_numpy(t_stft).cuda())
+    tr32.apply_gradients(1)
+    l32 = tr32.forward_backward(x, torch.from_numpy(t_mel).cuda(), torch.from_numpy(t_stft).cuda()).cpu().numpy()
+    assert not tr32._g16
+    assert np.abs(l2 - l32).max() < 2e-4 * np.abs(l32).max(), (l2, l32)
+
+
 def test_teacher_forced_stage2_matches_autograd(tmp_path):
     """use_target_mel_step2 (/root/reference/decoder.py:148-152, 258-260, 435-437): stage 2 is fed
     f_mel_pred * y_mel + (1 - f_mel_pred) * target_mel; f_mel_pred is a saved, non-trainable scalar raised per epoch
