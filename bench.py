@@ -505,8 +505,9 @@ def train_measure(rank, world, steps, warmup):
         zb = torch.empty((M, 128 * K), device='cuda')
         ms_bank = time_events(lambda: gemm16.gemm16(x16, rs, M, T, H, pairs, zb, 128 * K, col_scale=cs), 20)
         ms_split = time_events(lambda: gemm16.split16(pre, M, H, H, T), 20)
-        with modules.variable_store(dec.store), modules.variable_scope('decoder'), modules.variable_scope('step2'), \
-                modules.variable_scope('CBHG'):
+        import _vc
+        with _vc.options(f32_f16x3=0), modules.variable_store(dec.store), modules.variable_scope('decoder'), \
+                modules.variable_scope('step2'), modules.variable_scope('CBHG'):         # the f32-input MFMA kernel, for comparison
             ms_f32 = time_events(lambda: modules.conv1d_banks(pre.view(B, T, H), K=32, is_training=False), 20)
         fl_bank = 2.0 * 256 * 128 * 528 * B * T
         ach = fl_bank / (ms_bank * 1e-3) / 1e12
