@@ -73,6 +73,8 @@ const char* vc_target_arch(void);
  *   "cbhg_front_mi"  4 = 128-row blocks in the fused encoder front
  *   "f32_f16x3"      0 = float32 INFERENCE keeps its filter banks / post-bank projections on the f32-input MFMA kernels
  *                    (default: three float16 products of exactly split operands, vc_gemm16: float32-accurate)
+ *   "gru_f32_wide"   0 = float32 INFERENCE recurrences of more than 128 units stay on the streaming kernel (default: the
+ *                    training forward kernel, which keeps half of the 786 KB of weights resident: 15.8 -> 3.0 ms at 64 windows)
  *   "gemm16_split"   vc_gemm16, single-pair launches: ways K is split over workgroups (1..8) + 16 * block map (0 = the splits
  *                    of a row tile on one XCD, 1 = one K range per XCD: ways must divide 8); default: chosen from the shape
  * All alternatives compute the same function (tests compare them).  Three more names, "ablate_bank256",

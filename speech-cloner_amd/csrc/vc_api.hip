@@ -23,7 +23,7 @@ static std::atomic<int> g_opt[OPT_COUNT];
 static const struct { const char* name; Option id; bool ablate; } k_opts[] = {
     {"bank256", OPT_BANK256, false}, {"bank256_xcd", OPT_BANK256_XCD, false}, {"conv256", OPT_CONV256, false},
     {"conv256_min_k", OPT_CONV256_MINK, false}, {"conv256_wm", OPT_CONV256_WM, false}, {"proj256", OPT_PROJ256, false}, {"proj256_split", OPT_PROJ256_SPLIT, false},
-    {"wgrad_xcd", OPT_WGRAD_XCD, false}, {"gru_mfma", OPT_GRU_MFMA, false}, {"gru_mfma4", OPT_GRU_MFMA4, false}, {"gru_small_mfma", OPT_GRU_SMALL_MFMA, false}, {"fe_fused", OPT_FE_FUSED, false}, {"fe_fused_spin", OPT_FE_FUSED_SPIN, false}, {"gru_train_resident", OPT_GRU_TRAIN_RESIDENT, false}, {"prenet_lds", OPT_PRENET_LDS, false}, {"cbhg_front_mi", OPT_CBHG_FRONT_MI, false}, {"gemm16_split", OPT_GEMM16_SPLIT, false}, {"f32_f16x3", OPT_F32_F16X3, false},
+    {"wgrad_xcd", OPT_WGRAD_XCD, false}, {"gru_mfma", OPT_GRU_MFMA, false}, {"gru_mfma4", OPT_GRU_MFMA4, false}, {"gru_small_mfma", OPT_GRU_SMALL_MFMA, false}, {"fe_fused", OPT_FE_FUSED, false}, {"fe_fused_spin", OPT_FE_FUSED_SPIN, false}, {"gru_train_resident", OPT_GRU_TRAIN_RESIDENT, false}, {"prenet_lds", OPT_PRENET_LDS, false}, {"cbhg_front_mi", OPT_CBHG_FRONT_MI, false}, {"gemm16_split", OPT_GEMM16_SPLIT, false}, {"f32_f16x3", OPT_F32_F16X3, false}, {"gru_f32_wide", OPT_GRU_F32_WIDE, false},
     {"ablate_bank256", OPT_ABLATE_BANK256, true}, {"ablate_bank256_only", OPT_ABLATE_BANK256_ONLY, true},
     {"ablate_cbhg_front", OPT_ABLATE_CBHG_FRONT, true},
 };

@@ -46,6 +46,7 @@ enum Option {
     OPT_PRENET_LDS,       // 0: every wave of prenet_chain streams the weights itself (default: shared through LDS)
     OPT_GRU_TRAIN_RESIDENT,   // 0: the float32 training recurrences stream all their weights from L2 every step
     OPT_CBHG_FRONT_MI,    // 4: 128-row blocks in cbhg_small_kernel (default 2)
+    OPT_GRU_F32_WIDE,     // 0: float32 inference recurrences of more than 128 units stay on gru_generic_kernel (default: the training forward kernel)
     OPT_F32_F16X3,        // 0: float32 inference convolutions stay on the f32-input MFMA kernels (default: vc_gemm16)
     OPT_GEMM16_SPLIT,     // vc_gemm16 single-pair launches: K split ways (1..8) + 16 * block map (0: a row tile's splits on one XCD, 1: a K range per XCD); default: automatic
     OPT_ABLATE_BANK256,   // -DVC_ABLATE only: bit mask, see vc_bank256.h

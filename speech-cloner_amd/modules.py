@@ -559,6 +559,16 @@ def _gru_recurrence(xproj, N_, T_, H, wh_fw, wh_bw):
     store = _store()
     x = xproj
     out = torch.empty((N_, T_, 2 * H), dtype=store.dtype, device=x.device)
+    if store.dtype == torch.float32 and 128 < H <= 1024 and _vc.get_option('gru_f32_wide') != 0:
+        # float32 weights of more than 128 units do not fit a CU's registers: the inference kernels stream all 786 KB of
+        # them every step (15.8 ms for 64 windows at 256 units).  The TRAINING forward kernel (vc_gru_train_forward) keeps
+        # half of them resident and is the same recurrence (3.0 ms, results equal to 5e-7); what it saves for the
+        # backward pass goes to scratch.
+        gates = torch.empty((2, N_ * T_, 3 * H), dtype=torch.float32, device=x.device)
+        rh = torch.empty((2, N_ * T_, H), dtype=torch.float32, device=x.device)
+        _vc.check(_vc.lib().vc_gru_train_forward(xproj.data_ptr(), wh_fw.data_ptr(), wh_bw.data_ptr(), N_, T_, H,
+                                                 out.data_ptr(), gates.data_ptr(), rh.data_ptr(), _vc.current_stream()))
+        return out
     nws = _vc.lib().vc_gru_workspace_bytes(H, store.vc_dtype)
     ws = torch.empty((max(nws, 16),), dtype=torch.uint8, device=x.device)
     _vc.check(_vc.lib().vc_gru_bidir(xproj.data_ptr(), wh_fw.data_ptr(), wh_bw.data_ptr(), store.vc_dtype,

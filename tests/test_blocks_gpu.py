@@ -699,3 +699,21 @@ def test_summed_groups_is_the_banks_data_gradient(N, T, K, H, S):
     assert d < 2e-5 * max(1.0, ref.abs().max().item()), d
     with pytest.raises(_vc.VCError):                      # partial tiles carry no epilogue terms
         modules.gemm_launch(dZ.view(M, F * K), M, T, F, F * K, H, groups, out, H, _vc.VC_F32, R=res, ldr=H, out_f32=True, sum_groups=2)
+
+
+@pytest.mark.parametrize('H,N', [(256, 6), (192, 3)])
+def test_wide_float32_recurrence_on_the_training_forward_kernel_equals_the_streaming_kernel(H, N):
+    """float32 inference recurrences of more than 128 units (modules.gru, /root/reference/modules.py:168-204) run on the
+    training step's forward kernel, which keeps half of the weights resident (option gru_f32_wide = 0: the streaming
+    kernel that re-reads all of them every step).  Same GRUCell arithmetic in float32: the two agree to 2e-6."""
+    import modules
+    T = 400
+    st = modules.VariableStore('float32')
+    x = (torch.randn(N, T, H, generator=torch.Generator().manual_seed(H + N)) * 0.5).cuda()
+    outs = {}
+    for opt in (-1, 0):
+        with _vc.options(gru_f32_wide=opt), modules.variable_store(st), modules.variable_scope('g'):
+            outs[opt] = modules.gru(x, num_units=H, bidirection=True)
+    assert outs[-1].shape == (N, T, 2 * H)
+    d = float((outs[-1] - outs[0]).abs().max())
+    assert d < 2e-6, d
