@@ -371,11 +371,13 @@ class decoder_specs:
         x = self._to_device(inputs, self._input_width(), 'decoder input')
         tm = self._to_device(target_mel, c['steps_v'][0]['n_output'], 'target_mel')
         ts = self._to_device(target_stft, c['steps_v'][1]['n_output'], 'target_stft')
-        losses = tr.forward_backward(x, tm, ts)
+        tr.forward_backward(x, tm, ts)
         world = torch.distributed.get_world_size() if (torch.distributed.is_available() and
                                                         torch.distributed.is_initialized()) else 1
         global_step = tr.apply_gradients(world)
-        mel_loss, stft_loss = (np.float32(v) for v in losses.cpu().numpy())
+        # (the losses were copied to the host behind the forward pass: no wait for the backward pass / Adam here; the next
+        # step's launches queue behind them on the same stream)
+        mel_loss, stft_loss = (np.float32(v) for v in tr.losses_on_host())
         if c['loss_type'] == 'log':
             loss = np.float32(np.log(mel_loss) + np.log(stft_loss))
         else:

@@ -183,6 +183,11 @@ class StageTrainer:
         self._pending = []                           # gradient buckets already being all-reduced (data parallel)
         self.overlap_allreduce = True                # False: one blocking all-reduce in apply_gradients (tests)
         self.losses = torch.zeros(2, dtype=torch.float32, device=dev)
+        # the two scalars a training step returns to its caller are known after the FORWARD pass: copied to pinned host
+        # memory right there, with an event, so that exec_train_step waits for that copy only -- not for the backward pass,
+        # Adam and the weight re-layouts behind it, which the next step's launches simply queue behind
+        self._loss_host = torch.zeros(2, dtype=torch.float32).pin_memory() if torch.cuda.is_available() else None
+        self._loss_event = torch.cuda.Event() if torch.cuda.is_available() else None
         self.export_routing = False                  # True: keep every relu / max-pool decision of the step (parity tests)
         # The big convolutions (filter bank, post-bank projection, and their data gradients) as three float16 MFMA products
         # of exactly split float32 operands (gemm16.py; float32 accuracy, 2-3x the f32-MFMA rate).  'train_f16x3': false
@@ -734,6 +739,13 @@ class StageTrainer:
             dX0 = self._dgrad_dense(dZ1, E, E, W1p, M, T_)
         return dX0
 
+    def losses_on_host(self):
+        """The last forward pass's [mel_loss, stft_loss] as numpy float32, waiting for nothing but their own copy."""
+        if self._loss_host is None:
+            return self.losses.cpu().numpy()
+        self._loss_event.synchronize()
+        return self._loss_host.numpy().copy()
+
     def _join_side(self):
         """The current stream waits for everything this trainer issued to its side stream."""
         if self._side is not None:
@@ -897,6 +909,9 @@ class DecoderTrainer(StageTrainer):
                                          _p(self.losses[0:1]), _p(self.loss_ws), _st()))
             _vc.check(_lib().vc_mse_loss(_p(self.y_stft), _p(target_stft), M * n2, ws, _p(dY2), n2, y2.shape[1],
                                          _p(self.losses[1:2]), _p(self.loss_ws), _st()))
+            if self._loss_host is not None:
+                self._loss_host.copy_(self.losses, non_blocking=True)
+                self._loss_event.record()
             if not backward:
                 return self.losses
             if c['loss_type'] == 'log':          # d log(L) = dL / L  (host round trip for the two scalars)
