@@ -132,8 +132,17 @@ class VariableStore:
     def trainable_names(self, prefix=''):
         return [n for n in self.order if n.startswith(prefix) and n not in self.non_trainable]
 
-    def invalidate(self):
-        self._cache.clear()
+    def invalidate(self, prefix=None):
+        """Drop the kernel-layout copies derived from the weights -- all of them, or (``prefix``) only those of the
+        variables under one scope: a decoder that trains on top of a FROZEN encoder in the same store must not make the
+        encoder rebuild its copies (dozens of small launches at the head of every training step)."""
+        if prefix is None:
+            self._cache.clear()
+        else:
+            pre = prefix.rstrip('/')
+            for k in [k for k in self._cache if isinstance(k, tuple) and any(
+                    isinstance(e, str) and (e == pre or e.startswith(pre + '/')) for e in k[1:])]:
+                del self._cache[k]
         self.version = getattr(self, 'version', 0) + 1      # anything derived from the weights outside this cache checks it
 
     def cached(self, key, fn):

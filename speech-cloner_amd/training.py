@@ -817,8 +817,9 @@ class StageTrainer:
         _vc.check(_lib().vc_adam_step(_p(self.flat), _p(self.grad), _p(self.m), _p(self.v), self.total, lr_t, b1, b2, eps,
                                       1.0 / world, _st()))
         if getattr(self, '_layout_tab', None) is None:
-            self._conv_seen = {k_: v_ for k_, v_ in self.store._cache.items() if isinstance(k_, tuple) and k_[0] == 'conv'}
-        self.store.invalidate()                   # kernel-layout copies are stale now ...
+            self._conv_seen = {k_: v_ for k_, v_ in self.store._cache.items() if isinstance(k_, tuple) and k_[0] == 'conv'
+                               and str(k_[1]).startswith(self.dec._scope + '/')}
+        self.store.invalidate(self.dec._scope)    # this model's kernel-layout copies are stale now (a frozen encoder's in the same store are not) ...
         self._refresh_conv_layouts()              # ... except the convolutions', rewritten in place by one launch
         self._refresh_w16_async()
         self.dec.opt_state[self.opt_scope + '/global_step'] = np.int32(t)

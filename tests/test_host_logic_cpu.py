@@ -342,3 +342,21 @@ def test_gradient_buckets_cover_the_arena_exactly_once(monkeypatch):
     te = training.EncoderTrainer(enc)
     te._complete_exchange()
     assert covered(te) == [(0, te.total)]
+
+
+def test_scope_selective_invalidation_keeps_a_frozen_models_layout_copies():
+    """A decoder trains on top of a frozen encoder in ONE VariableStore: after Adam only the decoder's kernel-layout
+    copies are stale.  invalidate(prefix) drops exactly the cache entries whose scope lies under the prefix (and still
+    bumps the version every outside cache checks); invalidate() drops everything."""
+    import types
+    import modules
+    st = modules.VariableStore.__new__(modules.VariableStore)
+    st._cache = {('conv', 'encoder/CBHG/conv1d_1'): 1, ('bn', 'encoder/prenet'): 2, ('dense', 'decoder/step1/prenet/dense1'): 3,
+                 ('g16conv', 'decoder/step2/CBHG/conv1d_1', 'conv1d_1'): 4, ('eye', 80): 5, ('gru', 'decoder2/x'): 6,
+                 ('lstm', 'decoder', True): 7}
+    st.version = 3
+    st.invalidate('decoder')
+    assert set(st._cache) == {('conv', 'encoder/CBHG/conv1d_1'), ('bn', 'encoder/prenet'), ('eye', 80), ('gru', 'decoder2/x')}
+    assert st.version == 4
+    st.invalidate()
+    assert st._cache == {} and st.version == 5
